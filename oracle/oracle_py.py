@@ -1,0 +1,160 @@
+"""ctypes binding of the CPU oracle (oracle/libufm_oracle.so).
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and the
+cpu_baseline leg of bench.py.  The product path never imports this module.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+ALGO_FD, ALGO_SG, ALGO_DFM = 0, 1, 2
+
+
+def build():
+    subprocess.check_call(["make", "-s", "-C", _HERE])
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        so = os.path.join(_HERE, "libufm_oracle.so")
+        if not os.path.exists(so):
+            build()
+        L = C.CDLL(so)
+        vp, f, i = C.c_void_p, C.c_float, C.c_int
+        L.orc_create.restype = vp
+        L.orc_create.argtypes = [i, i, i]
+        L.orc_destroy.argtypes = [vp]
+        L.orc_reset.argtypes = [vp]
+        L.orc_set_occupancy_threshold.argtypes = [vp, f]
+        L.orc_set_heuristic_multiplier.argtypes = [vp, f]
+        L.orc_set_map.argtypes = [vp, C.c_void_p, i, i]
+        L.orc_patch_map.argtypes = [vp, C.c_void_p, i, i, i, i]
+        L.orc_set_start.argtypes = [vp, f, f]
+        L.orc_set_goal.argtypes = [vp, f, f]
+        L.orc_step.argtypes = [vp]
+        L.orc_step.restype = i
+        L.orc_field_dims.argtypes = [vp, C.POINTER(i), C.POINTER(i)]
+        for n in ("orc_g", "orc_rhs", "orc_inmap", "orc_bptr"):
+            getattr(L, n).restype = C.c_void_p
+            getattr(L, n).argtypes = [vp]
+        for n in ("orc_num_expanded", "orc_num_updated", "orc_map_size", "orc_queue_size"):
+            getattr(L, n).restype = C.c_ulong
+            getattr(L, n).argtypes = [vp]
+        for n in ("orc_u_time_ms", "orc_p_time_ms"):
+            getattr(L, n).restype = f
+            getattr(L, n).argtypes = [vp]
+        L.orc_top_key.argtypes = [vp, C.POINTER(f), C.POINTER(f)]
+        _LIB = L
+    return _LIB
+
+
+class OraclePlanner:
+    """Mirror of the reference planner surface (ReplannerBase.h:39-123)."""
+
+    def __init__(self, algo, opt_lvl=0, use_heuristic=False):
+        self.L = lib()
+        self.h = self.L.orc_create(algo, opt_lvl, int(use_heuristic))
+        if not self.h:
+            raise ValueError("bad algo/opt_lvl")
+        self.algo, self.opt_lvl = algo, opt_lvl
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.L.orc_destroy(self.h)
+            self.h = None
+
+    def reset(self):
+        self.L.orc_reset(self.h)
+
+    def set_occupancy_threshold(self, t):
+        self.L.orc_set_occupancy_threshold(self.h, float(t))
+
+    def set_heuristic_multiplier(self, m):
+        self.L.orc_set_heuristic_multiplier(self.h, float(m))
+
+    def set_map(self, m):
+        m = np.ascontiguousarray(m, dtype=np.uint8)
+        length, width = m.shape
+        self.L.orc_set_map(self.h, m.ctypes.data, width, length)
+
+    def patch_map(self, patch, x, y):
+        patch = np.ascontiguousarray(patch, dtype=np.uint8)
+        h, w = patch.shape
+        self.L.orc_patch_map(self.h, patch.ctypes.data, int(x), int(y), w, h)
+
+    def set_start(self, x, y):
+        self.L.orc_set_start(self.h, float(x), float(y))
+
+    def set_goal(self, x, y):
+        self.L.orc_set_goal(self.h, float(x), float(y))
+
+    def step(self):
+        return self.L.orc_step(self.h)
+
+    # ---- field views (copies) ----
+    def dims(self):
+        a, b = C.c_int(), C.c_int()
+        self.L.orc_field_dims(self.h, C.byref(a), C.byref(b))
+        return a.value, b.value
+
+    def _arr(self, fn, dtype, mult=1):
+        nx, ny = self.dims()
+        ptr = fn(self.h)
+        if not ptr:
+            return None
+        n = nx * ny * mult
+        buf = (C.c_char * (n * np.dtype(dtype).itemsize)).from_address(ptr)
+        a = np.frombuffer(buf, dtype=dtype).copy()
+        return a.reshape(nx, ny) if mult == 1 else a.reshape(nx, ny, mult)
+
+    def g(self):
+        return self._arr(self.L.orc_g, np.float32)
+
+    def rhs(self):
+        return self._arr(self.L.orc_rhs, np.float32)
+
+    def inmap(self):
+        return self._arr(self.L.orc_inmap, np.uint8)
+
+    @property
+    def num_expanded(self):
+        return self.L.orc_num_expanded(self.h)
+
+    @property
+    def num_updated(self):
+        return self.L.orc_num_updated(self.h)
+
+    @property
+    def map_size(self):
+        return self.L.orc_map_size(self.h)
+
+    @property
+    def queue_size(self):
+        return self.L.orc_queue_size(self.h)
+
+    @property
+    def u_time(self):
+        return self.L.orc_u_time_ms(self.h)
+
+    @property
+    def p_time(self):
+        return self.L.orc_p_time_ms(self.h)
+
+    def top_key(self):
+        a, b = C.c_float(), C.c_float()
+        self.L.orc_top_key(self.h, C.byref(a), C.byref(b))
+        return a.value, b.value
+
+    def trusted_mask(self):
+        """Elements whose value the reference guarantees final after step():
+        locally consistent (G==RHS<inf) and, D*-Lite invariant, with
+        G <= key at the top of the queue (NO_HEURISTIC keys)."""
+        g, rhs = self.g(), self.rhs()
+        k1, _ = self.top_key()
+        return (g == rhs) & np.isfinite(g) & (g <= k1)

@@ -1,0 +1,68 @@
+/*
+ * ufm_oracle.h -- TEST INFRASTRUCTURE ONLY (parity checker + CPU baseline).
+ *
+ * CPU restatement, in plain C, of the reference's priority-queue driven
+ * D*-Lite style replanners (Field D*, Shifted-Grid FM, Multi-Stencil DFM).
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may
+ * load this library.  The product path (libufm.so, HIP) never links it.
+ *
+ * PARITY PINNING STATUS: "parity unpinned" in the strict sense -- the
+ * reference ships no golden vectors / known-answer tests for this path and
+ * cannot be compiled in this image (its three header-only dependencies are
+ * un-vendored empty submodules; writing stand-ins for them is not allowed).
+ * The restatement follows the reference sources line by line (citations in
+ * ufm_oracle.c) and is cross-checked against the known answers SURVEY.md
+ * App. E recorded for the reference's own `noise-trap` bitmap.
+ */
+#ifndef UFM_ORACLE_H
+#define UFM_ORACLE_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct orc_planner orc_t;
+
+enum { ORC_ALGO_FD = 0, ORC_ALGO_SG = 1, ORC_ALGO_DFM = 2 };
+
+#define ORC_LOOP_OK 0
+#define ORC_LOOP_FAILURE_NO_GRAPH (-1)
+#define ORC_LOOP_FAILURE_NO_GOAL (-2)
+
+orc_t *orc_create(int algo, int opt_lvl, int use_heuristic);
+void orc_destroy(orc_t *p);
+
+void orc_reset(orc_t *p);
+void orc_set_occupancy_threshold(orc_t *p, float thr);
+void orc_set_heuristic_multiplier(orc_t *p, float m);
+/* copies the raster (the reference shares and mutates the caller's) */
+void orc_set_map(orc_t *p, const uint8_t *map, int width, int length);
+void orc_patch_map(orc_t *p, const uint8_t *patch, int x, int y, int w, int h);
+void orc_set_start(orc_t *p, float x, float y);
+void orc_set_goal(orc_t *p, float x, float y);
+int orc_step(orc_t *p);
+
+/* field view: dense row-major [nx][ny]; nodes: (L+1)x(W+1), cells: LxW.
+ * Elements never inserted into the reference's ExpandedMap read (inf,inf)
+ * and have inmap == 0. */
+int orc_field_dims(const orc_t *p, int *nx, int *ny);
+const float *orc_g(const orc_t *p);
+const float *orc_rhs(const orc_t *p);
+const uint8_t *orc_inmap(const orc_t *p);
+const int32_t *orc_bptr(const orc_t *p); /* level>=1: linear index (DFM: 2 per elem), else NULL */
+
+unsigned long orc_num_expanded(const orc_t *p);
+unsigned long orc_num_updated(const orc_t *p);
+unsigned long orc_map_size(const orc_t *p);
+unsigned long orc_queue_size(const orc_t *p);
+float orc_u_time_ms(const orc_t *p);
+float orc_p_time_ms(const orc_t *p);
+/* key at the top of the queue after the last step (inf,inf when empty) */
+void orc_top_key(const orc_t *p, float *k1, float *k2);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
