@@ -1,0 +1,117 @@
+/*
+ * ufm.h -- C ABI of the MI355X cost-propagation engine (libufm.so).
+ *
+ * This is the drop-in boundary for the grid-sweep hot path of the reference
+ * replanners (Field D*, Shifted-Grid FM / MFD*, Multi-Stencil DFM).  Each
+ * entry point replaces one member of the reference's C++ planner surface
+ * (paths relative to the reference tree); the header-only C++ classes in
+ * unige-tasi-path-planners_amd/include/ forward to these calls.
+ *
+ * Conventions: plain pointers and sizes, no C++/torch types, no exceptions.
+ * Every call returns UFM_OK (0) or a negative code; ufm_step additionally
+ * returns the reference's LOOP_* codes (ReplannerBase.h:22-24).
+ * Coordinates follow the reference: x = row (0..length), y = column
+ * (0..width); rasters are row-major uint8 [length][width] (Graph.cpp:31-34).
+ * A handle is not thread-safe; distinct handles are independent.
+ */
+#ifndef UFM_H
+#define UFM_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct ufm_planner ufm_t;
+
+/* planner family: FieldDPlanner / ShiftedGridPlanner / DFMPlanner */
+enum { UFM_ALGO_FD = 0, UFM_ALGO_SG = 1, UFM_ALGO_DFM = 2 };
+
+/* return codes */
+#define UFM_OK 0
+#define UFM_LOOP_FAILURE_NO_GRAPH (-1) /* ReplannerBase.h:23 */
+#define UFM_LOOP_FAILURE_NO_GOAL (-2)  /* ReplannerBase.h:24 */
+#define UFM_ERR_INVALID (-22)          /* bad argument */
+#define UFM_ERR_NOMEM (-12)
+#define UFM_ERR_NOT_CONVERGED (-75)    /* sweep cap hit (never expected) */
+#define UFM_ERR_HIP_BASE (-100)        /* HIP error e  ->  -100 - e */
+
+/* Per-step statistics; u_ms/p_ms/updated/expanded mirror the public members
+ * ReplannerBase::u_time, p_time, num_nodes_updated, num_nodes_expanded
+ * (ReplannerBase.h:37,144-145). */
+typedef struct ufm_stats {
+    float u_ms;                /* init / patch seeding + invalidation (raise) phase */
+    float p_ms;                /* propagation (lower) phase + finalisation */
+    uint64_t updated;          /* distinct elements seeded by map patches (num_nodes_updated) */
+    uint64_t expanded;         /* distinct elements whose G changed in this step */
+    uint64_t tile_visits;      /* tile relaxations (one LDS-resident tile sweep each) */
+    uint64_t tile_iters;       /* in-LDS sweeps summed over tile visits */
+    uint64_t elem_evals;       /* element RHS evaluations actually executed */
+    uint32_t launches;         /* relax kernel launches in this step */
+    uint32_t raise_launches;   /* of which in the invalidation phase */
+    float kernel_ms;           /* summed relax-kernel time (HIP events) if profiling is on, else 0 */
+} ufm_stats;
+
+/* ---- lifetime: `PlannerT<OPT_LVL> planner{}` (e.g. Tests/Planners/FDSTAR/main.cpp:77) ---- */
+int ufm_create(ufm_t **out, int algo, int opt_lvl, int use_heuristic, int device_id);
+int ufm_destroy(ufm_t *p);
+
+/* ---- ReplannerBase.h:39-108 ---- */
+int ufm_reset(ufm_t *p);                                  /* reset()                      :39-41 */
+int ufm_set_occupancy_threshold(ufm_t *p, float thr);     /* set_occupancy_threshold      :77-79, Graph.cpp:18-20 */
+int ufm_set_heuristic_multiplier(ufm_t *p, float mult);   /* set_heuristic_multiplier     :81-83 */
+/* set_map :85-88 / Graph::init Graph.cpp:22-29.  The raster is copied to HBM. */
+int ufm_set_map(ufm_t *p, const uint8_t *host_map, int width, int length);
+/* patch_map :90-92 / Graph::update Graph.cpp:36-51.  patch is row-major
+ * uint8 [h][w] placed with its first element at cell (x, y).  Changed cells
+ * are detected on the device; patches accumulate until the next step(). */
+int ufm_patch_map(ufm_t *p, const uint8_t *host_patch, int x, int y, int w, int h);
+int ufm_set_start(ufm_t *p, float x, float y);            /* set_start :94-97 */
+int ufm_set_goal(ufm_t *p, float x, float y);             /* set_goal  :99-108 */
+
+/* step() :43-75.  Synchronous: returns once the field has converged.
+ * stats may be NULL.  Returns UFM_OK(=LOOP_OK) / LOOP_FAILURE_* / error. */
+int ufm_step(ufm_t *p, ufm_stats *stats);
+
+/* ---- device-resident inputs (same semantics, pointers are HBM addresses on
+ * the planner's device; used when maps / patches already live in HBM, e.g.
+ * after an RCCL broadcast) ---- */
+int ufm_set_map_device(ufm_t *p, const uint8_t *dev_map, int width, int length);
+int ufm_patch_map_device(ufm_t *p, const uint8_t *dev_patch, int x, int y, int w, int h);
+
+/* ---- field read-back: replaces ExpandedMap::get_g / get_rhs / get_g_rhs
+ * (ExpandedMap.h:55-65) over a rectangle of elements (nodes for FD/SG,
+ * cells for DFM).  g / rhs are row-major [nx][ny] host buffers, either may
+ * be NULL.  Unreached elements read +inf. ---- */
+int ufm_field_dims(const ufm_t *p, int *nx, int *ny);
+int ufm_read_field(ufm_t *p, int x0, int y0, int nx, int ny, float *g, float *rhs);
+/* current raster (after patches), row-major [length][width] */
+int ufm_read_map(ufm_t *p, uint8_t *host_map);
+
+/* ---- measurement hooks ---- */
+int ufm_set_profiling(ufm_t *p, int enable);   /* HIP-event timing of every relax launch */
+void *ufm_stream(ufm_t *p);                    /* hipStream_t the kernels run on */
+const char *ufm_version(void);
+
+/* ---- batch of independent map instances on one device (BASELINE config 4).
+ * Every map of the batch has the same size / algo; a batch step advances all
+ * maps in one set of launches (tiles of all maps share the active lists). ---- */
+typedef struct ufm_batch ufm_batch_t;
+int ufm_batch_create(ufm_batch_t **out, int n_maps, int algo, int opt_lvl, int use_heuristic, int device_id);
+int ufm_batch_destroy(ufm_batch_t *b);
+int ufm_batch_size(const ufm_batch_t *b);
+int ufm_batch_set_occupancy_threshold(ufm_batch_t *b, float thr);
+int ufm_batch_set_map(ufm_batch_t *b, int i, const uint8_t *host_map, int width, int length);
+int ufm_batch_patch_map(ufm_batch_t *b, int i, const uint8_t *host_patch, int x, int y, int w, int h);
+int ufm_batch_set_start(ufm_batch_t *b, int i, float x, float y);
+int ufm_batch_set_goal(ufm_batch_t *b, int i, float x, float y);
+int ufm_batch_reset(ufm_batch_t *b, int i);
+int ufm_batch_step(ufm_batch_t *b, ufm_stats *stats);
+int ufm_batch_read_field(ufm_batch_t *b, int i, int x0, int y0, int nx, int ny, float *g, float *rhs);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* UFM_H */

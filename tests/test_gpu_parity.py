@@ -1,0 +1,95 @@
+"""-m gpu: HIP engine (through the C ABI) vs the CPU oracle."""
+import numpy as np
+import pytest
+
+import ufm_amd
+from helpers import ALGOS, check_parity, make_pair
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("algo", ["FD", "SG", "DFM"])
+@pytest.mark.parametrize("bitmap", ["noise-trap", "square", "wall-a", "wall-b"])
+def test_first_plan_reference_bitmaps(ref_bitmaps, algo, bitmap):
+    cost, (fx, fy, tx, ty) = ref_bitmaps[bitmap]
+    o, g = make_pair(ALGOS[algo], 0, cost, (fx, fy), (tx, ty))
+    assert o.step() == 0
+    assert g.step() == 0
+    n, nbad = check_parity(o, g, "%s/%s" % (algo, bitmap))
+    assert nbad == 0, "%d of %d trusted elements not bit-equal" % (nbad, n)
+    g.close()
+
+
+@pytest.mark.parametrize("algo", ["FD", "SG", "DFM"])
+@pytest.mark.parametrize("size", [(64, 64), (200, 136), (256, 256)])
+def test_first_plan_synthetic(algo, size):
+    width, length = size
+    cost = ufm_amd.synth.cost_map(1234, width, length)
+    start, goal = ufm_amd.synth.start_goal(width, length)
+    o, g = make_pair(ALGOS[algo], 0, cost, start, goal)
+    assert o.step() == 0 and g.step() == 0
+    n, nbad = check_parity(o, g, "%s/%dx%d" % (algo, width, length))
+    assert nbad == 0, "%d of %d trusted elements not bit-equal" % (nbad, n)
+    # the engine counts every element it finalised; the oracle's expansions are a subset
+    assert g.num_nodes_expanded >= n
+    g.close()
+
+
+@pytest.mark.parametrize("algo,lvl", [("FD", 0), ("FD", 1), ("SG", 0), ("SG", 2), ("DFM", 0), ("DFM", 1)])
+def test_replans_synthetic(algo, lvl):
+    width = length = 192
+    seed = 7
+    cost = ufm_amd.synth.cost_map(seed, width, length)
+    start, goal = ufm_amd.synth.start_goal(width, length)
+    o, g = make_pair(ALGOS[algo], lvl, cost, start, goal)
+    assert o.step() == 0 and g.step() == 0
+    check_parity(o, g, "%s first plan" % algo)
+    total_bad = 0
+    for k, s, top, left, patch in ufm_amd.synth.replan_script(seed, width, length, n_patches=25):
+        for p in (o, g):
+            p.patch_map(patch, top, left)
+            p.set_start(*s)
+        assert o.step() == 0 and g.step() == 0
+        assert g.num_nodes_updated == o.num_updated, (k, g.num_nodes_updated, o.num_updated)
+        n, nbad = check_parity(o, g, "%s replan %d" % (algo, k))
+        total_bad += nbad
+    assert total_bad == 0
+    # the device raster followed the patches
+    assert np.array_equal(g.read_map(width, length)[:40, :40], _patched(cost, seed, width, length, 25)[:40, :40])
+    g.close()
+
+
+def _patched(cost, seed, width, length, n):
+    c = cost.copy()
+    for k, s, top, left, patch in ufm_amd.synth.replan_script(seed, width, length, n_patches=n):
+        c[top:top + patch.shape[0], left:left + patch.shape[1]] = patch
+    return c
+
+
+def test_full_field_is_fixed_point_after_replans():
+    """Size-independent property: after any sequence of patches the converged
+    field equals the field of a fresh plan on the patched map (bitwise)."""
+    width = length = 320
+    seed = 99
+    cost = ufm_amd.synth.cost_map(seed, width, length)
+    start, goal = ufm_amd.synth.start_goal(width, length)
+    g = ufm_amd.Planner(ufm_amd.ALGO_FD, 1)
+    g.set_occupancy_threshold(1)
+    g.set_map(cost)
+    g.set_start(*start)
+    g.set_goal(*goal)
+    assert g.step() == 0
+    for k, s, top, left, patch in ufm_amd.synth.replan_script(seed, width, length, n_patches=12):
+        g.patch_map(patch, top, left)
+        g.set_start(*s)
+        assert g.step() == 0
+    inc = g.g()
+    f = ufm_amd.Planner(ufm_amd.ALGO_FD, 1)
+    f.set_occupancy_threshold(1)
+    f.set_map(_patched(cost, seed, width, length, 12))
+    f.set_start(*start)
+    f.set_goal(*goal)
+    assert f.step() == 0
+    fresh = f.g()
+    assert np.array_equal(inc, fresh)
+    g.close(); f.close()

@@ -1,0 +1,256 @@
+"""ctypes binding of include/ufm.h (libufm.so).  No CPU fallback."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+ALGO_FD, ALGO_SG, ALGO_DFM = 0, 1, 2
+LOOP_OK, LOOP_FAILURE_NO_GRAPH, LOOP_FAILURE_NO_GOAL = 0, -1, -2
+
+# every symbol include/ufm.h declares (checked by tests/test_capi_symbols.py)
+SYMBOLS = [
+    "ufm_create", "ufm_destroy", "ufm_reset", "ufm_set_occupancy_threshold",
+    "ufm_set_heuristic_multiplier", "ufm_set_map", "ufm_patch_map", "ufm_set_start",
+    "ufm_set_goal", "ufm_step", "ufm_set_map_device", "ufm_patch_map_device",
+    "ufm_field_dims", "ufm_read_field", "ufm_read_map", "ufm_set_profiling", "ufm_stream",
+    "ufm_version", "ufm_batch_create", "ufm_batch_destroy", "ufm_batch_size",
+    "ufm_batch_set_occupancy_threshold", "ufm_batch_set_map", "ufm_batch_patch_map",
+    "ufm_batch_set_start", "ufm_batch_set_goal", "ufm_batch_reset", "ufm_batch_step",
+    "ufm_batch_read_field",
+]
+
+
+class UfmError(RuntimeError):
+    pass
+
+
+class Stats(C.Structure):
+    _fields_ = [
+        ("u_ms", C.c_float), ("p_ms", C.c_float),
+        ("updated", C.c_uint64), ("expanded", C.c_uint64),
+        ("tile_visits", C.c_uint64), ("tile_iters", C.c_uint64), ("elem_evals", C.c_uint64),
+        ("launches", C.c_uint32), ("raise_launches", C.c_uint32),
+        ("kernel_ms", C.c_float),
+    ]
+
+    def as_dict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_}
+
+
+def library_path():
+    return os.path.join(_HERE, "libufm.so")
+
+
+def build_library():
+    """hipcc cross-compiles gfx950 without a GPU (seconds)."""
+    subprocess.check_call(["make", "-s", "-C", _HERE])
+
+
+def load_library():
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    so = library_path()
+    if not os.path.exists(so):
+        raise UfmError("libufm.so is not built (run `make -C unige-tasi-path-planners_amd` "
+                       "or __graft_entry__.build()); there is no CPU fallback")
+    L = C.CDLL(so)
+    vp, f, i = C.c_void_p, C.c_float, C.c_int
+    L.ufm_create.argtypes = [C.POINTER(vp), i, i, i, i]
+    L.ufm_destroy.argtypes = [vp]
+    L.ufm_reset.argtypes = [vp]
+    L.ufm_set_occupancy_threshold.argtypes = [vp, f]
+    L.ufm_set_heuristic_multiplier.argtypes = [vp, f]
+    L.ufm_set_map.argtypes = [vp, vp, i, i]
+    L.ufm_set_map_device.argtypes = [vp, vp, i, i]
+    L.ufm_patch_map.argtypes = [vp, vp, i, i, i, i]
+    L.ufm_patch_map_device.argtypes = [vp, vp, i, i, i, i]
+    L.ufm_set_start.argtypes = [vp, f, f]
+    L.ufm_set_goal.argtypes = [vp, f, f]
+    L.ufm_step.argtypes = [vp, C.POINTER(Stats)]
+    L.ufm_field_dims.argtypes = [vp, C.POINTER(i), C.POINTER(i)]
+    L.ufm_read_field.argtypes = [vp, i, i, i, i, vp, vp]
+    L.ufm_read_map.argtypes = [vp, vp]
+    L.ufm_set_profiling.argtypes = [vp, i]
+    L.ufm_stream.argtypes = [vp]
+    L.ufm_stream.restype = vp
+    L.ufm_version.restype = C.c_char_p
+    L.ufm_batch_create.argtypes = [C.POINTER(vp), i, i, i, i, i]
+    L.ufm_batch_destroy.argtypes = [vp]
+    L.ufm_batch_size.argtypes = [vp]
+    L.ufm_batch_set_occupancy_threshold.argtypes = [vp, f]
+    L.ufm_batch_set_map.argtypes = [vp, i, vp, i, i]
+    L.ufm_batch_patch_map.argtypes = [vp, i, vp, i, i, i, i]
+    L.ufm_batch_set_start.argtypes = [vp, i, f, f]
+    L.ufm_batch_set_goal.argtypes = [vp, i, f, f]
+    L.ufm_batch_reset.argtypes = [vp, i]
+    L.ufm_batch_step.argtypes = [vp, C.POINTER(Stats)]
+    L.ufm_batch_read_field.argtypes = [vp, i, i, i, i, i, vp, vp]
+    _LIB = L
+    return L
+
+
+def _chk(rc, what):
+    if rc != 0:
+        raise UfmError("%s failed with code %d" % (what, rc))
+
+
+class Planner:
+    """Mirror of the reference planner surface (ReplannerBase.h:39-123):
+    reset / set_occupancy_threshold / set_heuristic_multiplier / set_map /
+    patch_map / set_start / set_goal / step, public stats u_time, p_time,
+    num_nodes_updated, num_nodes_expanded, and a dense field view in place of
+    ExpandedMap::get_g / get_rhs."""
+
+    def __init__(self, algo, opt_lvl=0, use_heuristic=False, device=0):
+        self.L = load_library()
+        h = C.c_void_p()
+        _chk(self.L.ufm_create(C.byref(h), algo, opt_lvl, int(use_heuristic), device), "ufm_create")
+        self.h = h
+        self.algo = algo
+        self.stats = Stats()
+        self.u_time = 0.0
+        self.p_time = 0.0
+        self.num_nodes_updated = 0
+        self.num_nodes_expanded = 0
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.ufm_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def reset(self):
+        _chk(self.L.ufm_reset(self.h), "ufm_reset")
+
+    def set_occupancy_threshold(self, t):
+        _chk(self.L.ufm_set_occupancy_threshold(self.h, float(t)), "ufm_set_occupancy_threshold")
+
+    def set_heuristic_multiplier(self, m):
+        _chk(self.L.ufm_set_heuristic_multiplier(self.h, float(m)), "ufm_set_heuristic_multiplier")
+
+    def set_map(self, m):
+        m = np.ascontiguousarray(m, dtype=np.uint8)
+        length, width = m.shape
+        _chk(self.L.ufm_set_map(self.h, m.ctypes.data, width, length), "ufm_set_map")
+
+    def set_map_device(self, dev_ptr, width, length):
+        _chk(self.L.ufm_set_map_device(self.h, dev_ptr, width, length), "ufm_set_map_device")
+
+    def patch_map(self, patch, x, y):
+        patch = np.ascontiguousarray(patch, dtype=np.uint8)
+        h, w = patch.shape
+        _chk(self.L.ufm_patch_map(self.h, patch.ctypes.data, int(x), int(y), w, h), "ufm_patch_map")
+
+    def patch_map_device(self, dev_ptr, x, y, w, h):
+        _chk(self.L.ufm_patch_map_device(self.h, dev_ptr, int(x), int(y), int(w), int(h)), "ufm_patch_map_device")
+
+    def set_start(self, x, y):
+        _chk(self.L.ufm_set_start(self.h, float(x), float(y)), "ufm_set_start")
+
+    def set_goal(self, x, y):
+        _chk(self.L.ufm_set_goal(self.h, float(x), float(y)), "ufm_set_goal")
+
+    def set_profiling(self, on):
+        _chk(self.L.ufm_set_profiling(self.h, int(on)), "ufm_set_profiling")
+
+    def step(self):
+        rc = self.L.ufm_step(self.h, C.byref(self.stats))
+        if rc in (LOOP_FAILURE_NO_GRAPH, LOOP_FAILURE_NO_GOAL):
+            return rc
+        _chk(rc, "ufm_step")
+        self.u_time, self.p_time = self.stats.u_ms, self.stats.p_ms
+        self.num_nodes_updated = self.stats.updated
+        self.num_nodes_expanded = self.stats.expanded
+        return rc
+
+    def dims(self):
+        a, b = C.c_int(), C.c_int()
+        _chk(self.L.ufm_field_dims(self.h, C.byref(a), C.byref(b)), "ufm_field_dims")
+        return a.value, b.value
+
+    def read_field(self, x0=0, y0=0, nx=None, ny=None):
+        ex, ey = self.dims()
+        nx = ex - x0 if nx is None else nx
+        ny = ey - y0 if ny is None else ny
+        g = np.empty((nx, ny), dtype=np.float32)
+        rhs = np.empty((nx, ny), dtype=np.float32)
+        _chk(self.L.ufm_read_field(self.h, x0, y0, nx, ny, g.ctypes.data, rhs.ctypes.data), "ufm_read_field")
+        return g, rhs
+
+    def g(self):
+        return self.read_field()[0]
+
+    def read_map(self, width, length):
+        m = np.empty((length, width), dtype=np.uint8)
+        _chk(self.L.ufm_read_map(self.h, m.ctypes.data), "ufm_read_map")
+        return m
+
+
+class BatchPlanner:
+    """Batch of independent, equally sized map instances on one device."""
+
+    def __init__(self, n_maps, algo, opt_lvl=0, use_heuristic=False, device=0):
+        self.L = load_library()
+        h = C.c_void_p()
+        _chk(self.L.ufm_batch_create(C.byref(h), n_maps, algo, opt_lvl, int(use_heuristic), device), "ufm_batch_create")
+        self.h = h
+        self.n = n_maps
+        self.algo = algo
+        self.stats = Stats()
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.ufm_batch_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_occupancy_threshold(self, t):
+        _chk(self.L.ufm_batch_set_occupancy_threshold(self.h, float(t)), "ufm_batch_set_occupancy_threshold")
+
+    def set_map(self, i, m):
+        m = np.ascontiguousarray(m, dtype=np.uint8)
+        length, width = m.shape
+        _chk(self.L.ufm_batch_set_map(self.h, i, m.ctypes.data, width, length), "ufm_batch_set_map")
+        self._dims = (length + (0 if self.algo == ALGO_DFM else 1), width + (0 if self.algo == ALGO_DFM else 1))
+
+    def patch_map(self, i, patch, x, y):
+        patch = np.ascontiguousarray(patch, dtype=np.uint8)
+        h, w = patch.shape
+        _chk(self.L.ufm_batch_patch_map(self.h, i, patch.ctypes.data, int(x), int(y), w, h), "ufm_batch_patch_map")
+
+    def set_start(self, i, x, y):
+        _chk(self.L.ufm_batch_set_start(self.h, i, float(x), float(y)), "ufm_batch_set_start")
+
+    def set_goal(self, i, x, y):
+        _chk(self.L.ufm_batch_set_goal(self.h, i, float(x), float(y)), "ufm_batch_set_goal")
+
+    def reset(self, i):
+        _chk(self.L.ufm_batch_reset(self.h, i), "ufm_batch_reset")
+
+    def step(self):
+        rc = self.L.ufm_batch_step(self.h, C.byref(self.stats))
+        if rc in (LOOP_FAILURE_NO_GRAPH, LOOP_FAILURE_NO_GOAL):
+            return rc
+        _chk(rc, "ufm_batch_step")
+        return rc
+
+    def read_field(self, i):
+        nx, ny = self._dims
+        g = np.empty((nx, ny), dtype=np.float32)
+        _chk(self.L.ufm_batch_read_field(self.h, i, 0, 0, nx, ny, g.ctypes.data, None), "ufm_batch_read_field")
+        return g

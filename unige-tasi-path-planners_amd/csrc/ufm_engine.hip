@@ -1,0 +1,882 @@
+// ufm_engine.hip -- MI355X (gfx950) cost-propagation engine behind include/ufm.h.
+//
+// What it replaces: the priority-queue driven G/RHS wavefront of the reference
+// replanners -- ReplannerBase::step (ProjectToolkit/include/ReplannerBase.h:43-75)
+// with FieldDPlanner / ShiftedGridPlanner / DFMPlanner init/update/plan
+// (FieldDStar/FieldDPlanner_impl.h:15-163, ShiftedGridFastMarching/
+// ShiftedGridPlanner_impl.h:9-231, DynamicFastMarching/DynamicFastMarching_impl.h:6-132).
+//
+// How: the serial D*-Lite expansion order is replaced by a block Fast Iterative
+// Method.  The field G lives densely in HBM; the domain is cut into 32x32-element
+// tiles; an active-tile list drives launches of k_relax, which stages one tile
+// (+1 halo) in LDS, sweeps it in place until it stops changing (wave-level
+// ballots keep idle 8x8 patches from re-evaluating), writes it back and
+// activates the neighbours whose halo changed.  The fixed point G = F(G) is
+// unique (costs >= 1), so it equals the reference's consistent field.
+// Map patches (cost increases) are handled by an invalidation ("raise") phase
+// -- an element whose value is no longer supported by its neighbours is reset
+// to +inf, transitively -- followed by the usual lowering phase.
+//
+// Arithmetic contract (bit parity with oracle/ufm_oracle.c): IEEE fp32, one
+// rounding per operation (-ffp-contract=off), correctly rounded sqrt.
+#include <hip/hip_runtime.h>
+
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "../../include/ufm.h"
+
+namespace {
+
+constexpr int T = 32;          // tile edge (elements)
+constexpr int GP = 40;         // LDS pitch of the G tile: rows 8 apart hit distinct banks
+constexpr int CP = 34;         // LDS pitch of the cost tile
+constexpr int NTHR = 1024;     // one element per lane, 16 waves, each owns an 8x8 patch
+constexpr int GPAD = 32;       // left padding (floats) so tile rows start 128-B aligned
+constexpr float SQRT2F = 1.41421356237309504880168872420969807856967187537694f;  // Macros.cpp:2
+
+enum { MODE_LOWER = 0, MODE_RAISE = 1 };
+
+struct DevCounters {
+    int cnt[3];                 // active-list lengths (ring of three)
+    int tcount;                 // touched-list length
+    int scount;                 // pending-seed-list length
+    int not_converged;
+    unsigned long long expanded;
+    unsigned long long tile_visits;
+    unsigned long long tile_iters;
+    unsigned long long elem_evals;
+};
+
+struct DevParams {
+    float *G;                   // [nmaps][rows][pitch], +inf padded
+    float *Gprev;               // snapshot of a tile at its first touch in a step
+    uint8_t *cost;              // [nmaps][L][W]
+    int *goal;                  // [nmaps][2]
+    int *list;                  // [3][NT] active tiles (global tile ids)
+    int *flag;                  // [3][NT]
+    int *touched;               // [NT]
+    int *tlist;                 // [NT]
+    int *sflag;                 // [NT] pending seeds (from patches)
+    int *slist;                 // [NT]
+    int *slist2;                // [NT] scratch
+    unsigned int *mark;         // [nmaps][markwords] bitmap of seeded elements
+    unsigned int *num_updated;  // [nmaps]
+    int *consume;               // [nmaps]
+    DevCounters *ctr;
+    int EX, EY;                 // elements per map (nodes or cells)
+    int L, W;                   // cells per map
+    int TX, TY, NTm, NT, nmaps;
+    int pitch;
+    int thr;                    // Graph::occupancy_threshold_uchar_
+    size_t gstride;             // floats per map in G
+    size_t cstride;             // bytes per map in cost
+    size_t mstride;             // words per map in mark
+};
+
+__device__ __forceinline__ void activate(const DevParams &P, int nb, int gt) {
+    if (atomicExch(&P.flag[nb * P.NT + gt], 1) == 0) {
+        const int k = atomicAdd(&P.ctr->cnt[nb], 1);
+        P.list[nb * P.NT + k] = gt;
+    }
+}
+
+// ---- update operators -------------------------------------------------------
+// ShiftedGridPlanner_impl.h:422-436 (+ InterpolatedTraversal.cpp:125-127,324-326,403-405)
+__device__ __forceinline__ float tri_sg(float g1, float g2, float c) {
+    const float f = g1 - g2;
+    const float tII = g1 + __fsqrt_rn(c * c - f * f);
+    const float tA = g2 + c * SQRT2F;
+    float r = (f * SQRT2F <= c) ? tII : tA;
+    r = (f <= 0.0f) ? (g1 + c) : r;
+    return (c == INFINITY) ? INFINITY : r;   // both g inf -> f NaN -> tA = inf
+}
+// FieldDPlanner_impl.h:292-319 (+ InterpolatedTraversal.cpp:8-10,125-127,236-238,324-326,403-405)
+// cb = CATH(c,b) is constant during a tile visit and passed in.
+__device__ __forceinline__ float tri_fd(float g1, float g2, float b, float c, float cb) {
+    const float f = g1 - g2;
+    const float tII = g1 + __fsqrt_rn(c * c - f * f);
+    const float tA = g2 + c * SQRT2F;
+    const bool cIII = (f <= 0.0f) || (f * f <= cb);
+    const bool cII = (f <= b) && (c > f * SQRT2F);
+    const bool cI = (f > b) && (c > b * SQRT2F);
+    const float r1 = cIII ? (g1 + b) : (cII ? tII : (cI ? ((g2 + b) + cb) : tA));
+    const float r2 = (f <= 0.0f) ? (g1 + c) : ((f * SQRT2F < c) ? tII : tA);
+    const float r = (c > b) ? r1 : r2;
+    const bool dead = (c == INFINITY) || ((g1 == INFINITY) && (g2 == INFINITY));
+    return dead ? INFINITY : r;
+}
+// DynamicFastMarching_impl.h:322-342
+__device__ __forceinline__ float q_dfm(float a, float b, float th) {
+    const float ga = fminf(a, b), gb = fmaxf(a, b);
+    const float d = gb - ga;
+    const float s = ((ga + gb) + __fsqrt_rn(2.0f * (th * th) - d * d)) * 0.5f;
+    return (th > d) ? s : (ga + th);        // both inf -> d NaN -> ga + th = inf
+}
+
+struct NodeCosts {   // the four cells around a node (Node.cpp:44-50) and FD's CATH(c,b) terms
+    float c00, c01, c10, c11;
+    float k0, k1, k2, k3, k4, k5, k6, k7;
+};
+
+template <int ALGO>
+__device__ __forceinline__ float eval_elem(const float *Gs, int lx, int ly, const NodeCosts &C) {
+    const float *ctr = Gs + (lx + 1) * GP + (ly + 1);
+    const float gN = ctr[-GP], gS = ctr[GP], gW = ctr[-1], gE = ctr[1];
+    const float gNW = ctr[-GP - 1], gNE = ctr[-GP + 1], gSW = ctr[GP - 1], gSE = ctr[GP + 1];
+    if (ALGO == UFM_ALGO_DFM) {
+        // DynamicFastMarching_impl.h:157-210 (best_cell :344-351 reduces to a min on values)
+        const float tau = C.c00;
+        const float ortho = q_dfm(fminf(gN, gS), fminf(gW, gE), tau);
+        const float diag = q_dfm(fminf(gNW, gSE), fminf(gSW, gNE), tau * SQRT2F);
+        return (diag < ortho) ? diag : ortho;
+    } else if (ALGO == UFM_ALGO_SG) {
+        // ShiftedGridPlanner_impl.h:258-264 over the 8 triangles of Graph.cpp:202-230
+        float r = tri_sg(gN, gNW, C.c00);
+        r = fminf(r, tri_sg(gW, gNW, C.c00));
+        r = fminf(r, tri_sg(gN, gNE, C.c01));
+        r = fminf(r, tri_sg(gE, gNE, C.c01));
+        r = fminf(r, tri_sg(gS, gSW, C.c10));
+        r = fminf(r, tri_sg(gW, gSW, C.c10));
+        r = fminf(r, tri_sg(gS, gSE, C.c11));
+        r = fminf(r, tri_sg(gE, gSE, C.c11));
+        return r;
+    } else {
+        // FieldDPlanner_impl.h:188-194; b = cell across the edge s-p1 (:322-337)
+        float r = tri_fd(gN, gNW, C.c01, C.c00, C.k0);
+        r = fminf(r, tri_fd(gW, gNW, C.c10, C.c00, C.k1));
+        r = fminf(r, tri_fd(gN, gNE, C.c00, C.c01, C.k2));
+        r = fminf(r, tri_fd(gE, gNE, C.c11, C.c01, C.k3));
+        r = fminf(r, tri_fd(gS, gSW, C.c11, C.c10, C.k4));
+        r = fminf(r, tri_fd(gW, gSW, C.c00, C.c10, C.k5));
+        r = fminf(r, tri_fd(gS, gSE, C.c10, C.c11, C.k6));
+        r = fminf(r, tri_fd(gE, gSE, C.c01, C.c11, C.k7));
+        return r;
+    }
+}
+
+// Graph::get_cost, Graph.cpp:262-268
+__device__ __forceinline__ float cell_cost(const DevParams &P, const uint8_t *cm, int cx, int cy) {
+    if (cx < 0 || cy < 0 || cx >= P.L || cy >= P.W) return INFINITY;
+    const int c = cm[(size_t)cx * P.W + cy];
+    return (c >= P.thr) ? INFINITY : (float)c;
+}
+
+// ---- the hot kernel: one workgroup relaxes one active tile at a time ----------
+template <int ALGO, int MODE>
+__global__ __launch_bounds__(NTHR) void k_relax(DevParams P, int buf, int max_iters) {
+    __shared__ float Gs[(T + 2) * GP];
+    __shared__ float Cs[(T + 1) * CP];
+    __shared__ int s_dirty[2][16];
+    __shared__ int s_misc[4];   // 0: first touch, 1: border-change mask, 2: wave evaluations
+
+    const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
+    const int lx = (w >> 2) * 8 + (lane >> 3), ly = (w & 3) * 8 + (lane & 7);   // compute mapping
+    const int io_r = tid >> 5, io_c = tid & 31;                                 // HBM mapping
+    const int nb = (buf + 1) % 3;
+    const int n = P.ctr->cnt[buf];
+    if (blockIdx.x == 0 && tid == 0) P.ctr->cnt[(buf + 2) % 3] = 0;
+    constexpr int CROWS = (ALGO == UFM_ALGO_DFM) ? T : T + 1;
+    constexpr int COFF = (ALGO == UFM_ALGO_DFM) ? 0 : 1;
+
+    for (int i = blockIdx.x; i < n; i += gridDim.x) {
+        const int gt = P.list[buf * P.NT + i];
+        const int m = gt / P.NTm, t = gt - m * P.NTm;
+        const int tx = t / P.TY, ty = t - tx * P.TY;
+        const int x0 = tx * T, y0 = ty * T;
+        float *Gm = P.G + (size_t)m * P.gstride;
+        const uint8_t *cm = P.cost + (size_t)m * P.cstride;
+
+        if (tid == 0) {
+            P.flag[buf * P.NT + gt] = 0;
+            const int first = atomicExch(&P.touched[gt], 1) == 0;
+            if (first) P.tlist[atomicAdd(&P.ctr->tcount, 1)] = gt;
+            s_misc[0] = first; s_misc[1] = 0; s_misc[2] = 0;
+        }
+        if (tid < 16) { s_dirty[0][tid] = 1; s_dirty[1][tid] = 0; }
+
+        // stage G tile + halo (rows padded by one, columns by GPAD: no bounds checks)
+        const size_t gidx = (size_t)(x0 + io_r + 1) * P.pitch + (y0 + io_c + GPAD);
+        const float gl0 = Gm[gidx];
+        Gs[(io_r + 1) * GP + io_c + 1] = gl0;
+        if (tid < 4 * T + 4) {
+            int hr, hc;
+            if (tid < T) { hr = -1; hc = tid; }
+            else if (tid < 2 * T) { hr = T; hc = tid - T; }
+            else if (tid < 3 * T) { hr = tid - 2 * T; hc = -1; }
+            else if (tid < 4 * T) { hr = tid - 3 * T; hc = T; }
+            else { hr = (tid & 2) ? T : -1; hc = (tid & 1) ? T : -1; }
+            Gs[(hr + 1) * GP + hc + 1] = Gm[(size_t)(x0 + hr + 1) * P.pitch + (y0 + hc + GPAD)];
+        }
+        // stage the cost tile as float (inf = obstacle / outside)
+        for (int e = tid; e < CROWS * CROWS; e += NTHR) {
+            const int cr = e / CROWS, cc = e - cr * CROWS;
+            Cs[cr * CP + cc] = cell_cost(P, cm, x0 + cr - COFF, y0 + cc - COFF);
+        }
+        __syncthreads();
+        if (s_misc[0]) P.Gprev[(size_t)m * P.gstride + gidx] = gl0;
+
+        float g = Gs[(lx + 1) * GP + ly + 1];
+        NodeCosts C;
+        C.c00 = Cs[lx * CP + ly];
+        if (ALGO != UFM_ALGO_DFM) {
+            C.c01 = Cs[lx * CP + ly + 1];
+            C.c10 = Cs[(lx + 1) * CP + ly];
+            C.c11 = Cs[(lx + 1) * CP + ly + 1];
+        }
+        if (ALGO == UFM_ALGO_FD) {   // CATH(c,b), Macros.h:12, per (c,b) pair of eval_elem
+            C.k0 = __fsqrt_rn(C.c00 * C.c00 - C.c01 * C.c01);
+            C.k1 = __fsqrt_rn(C.c00 * C.c00 - C.c10 * C.c10);
+            C.k2 = __fsqrt_rn(C.c01 * C.c01 - C.c00 * C.c00);
+            C.k3 = __fsqrt_rn(C.c01 * C.c01 - C.c11 * C.c11);
+            C.k4 = __fsqrt_rn(C.c10 * C.c10 - C.c11 * C.c11);
+            C.k5 = __fsqrt_rn(C.c10 * C.c10 - C.c00 * C.c00);
+            C.k6 = __fsqrt_rn(C.c11 * C.c11 - C.c10 * C.c10);
+            C.k7 = __fsqrt_rn(C.c11 * C.c11 - C.c01 * C.c01);
+        }
+        const bool is_goal = (x0 + lx == P.goal[2 * m]) && (y0 + ly == P.goal[2 * m + 1]);
+
+        int cur = 0, it = 0, wave_evals = 0;
+        bool conv = false;
+        for (; it < max_iters; ++it) {
+            int changed = 0;
+            if (s_dirty[cur][w]) {                       // wave-uniform
+                if (lane == 0) s_dirty[cur][w] = 0;
+                float nv = eval_elem<ALGO>(Gs, lx, ly, C);
+                if (is_goal) nv = 0.0f;                  // RHS(goal) = 0, *_impl.h init()
+                if (MODE == MODE_LOWER) {
+                    changed = (nv != g);                 // replace semantics: G <- F(G)
+                } else {
+                    changed = (g < INFINITY) && (nv > g);   // value lost its support
+                    nv = INFINITY;
+                }
+                if (changed) { g = nv; Gs[(lx + 1) * GP + ly + 1] = nv; }
+                const unsigned long long mask = __ballot(changed);
+                if (mask && lane < 9) {                  // wake the patches whose inputs changed
+                    const int dr = lane / 3 - 1, dc = lane % 3 - 1;
+                    unsigned long long sel = ~0ull;
+                    if (dr < 0) sel &= 0x00000000000000FFull; else if (dr > 0) sel &= 0xFF00000000000000ull;
+                    if (dc < 0) sel &= 0x0101010101010101ull; else if (dc > 0) sel &= 0x8080808080808080ull;
+                    const int pr = (w >> 2) + dr, pc = (w & 3) + dc;
+                    if ((mask & sel) && pr >= 0 && pr < 4 && pc >= 0 && pc < 4) s_dirty[cur ^ 1][pr * 4 + pc] = 1;
+                }
+                ++wave_evals;
+            }
+            cur ^= 1;
+            if (!__syncthreads_or(changed)) { conv = true; ++it; break; }
+        }
+        if (lane == 0 && wave_evals) atomicAdd(&s_misc[2], wave_evals);
+
+        // write back what changed; note which neighbours saw their halo change
+        const float gf = Gs[(io_r + 1) * GP + io_c + 1];
+        if (gf != gl0) {
+            Gm[gidx] = gf;
+            const int er = (io_r == 0) ? -1 : ((io_r == T - 1) ? 1 : 0);
+            const int ec = (io_c == 0) ? -1 : ((io_c == T - 1) ? 1 : 0);
+            int bits = 0;
+            if (er) bits |= 1 << ((er + 1) * 3 + 1);
+            if (ec) bits |= 1 << (3 + ec + 1);
+            if (er && ec) bits |= 1 << ((er + 1) * 3 + ec + 1);
+            if (bits) atomicOr(&s_misc[1], bits);
+        }
+        __syncthreads();
+        if (tid < 9) {
+            const int dr = tid / 3 - 1, dc = tid % 3 - 1;
+            if (tid == 4) {
+                if (!conv) activate(P, nb, gt);          // sweep cap hit: come back
+                atomicAdd(&P.ctr->tile_visits, 1ull);
+                atomicAdd(&P.ctr->tile_iters, (unsigned long long)it);
+                atomicAdd(&P.ctr->elem_evals, 64ull * (unsigned long long)s_misc[2]);
+            } else if (s_misc[1] & (1 << tid)) {
+                const int ntx = tx + dr, nty = ty + dc;
+                if (ntx >= 0 && ntx < P.TX && nty >= 0 && nty < P.TY) activate(P, nb, m * P.NTm + ntx * P.TY + nty);
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// ---- small control kernels -----------------------------------------------------
+__global__ void k_fill(float *p, size_t n, float v) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) p[i] = v;
+}
+
+// Graph::update (Graph.cpp:36-51) on the device + seeding of update()
+// (FD impl:127-136 corner nodes of changed cells; DFM impl:106-112 the cells).
+template <bool NODES>
+__global__ void k_patch(DevParams P, int m, const uint8_t *patch, int x, int y, int w, int h) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= w * h) return;
+    const int i = e / w, j = e - i * w;
+    const int cx = x + i, cy = y + j;
+    uint8_t *cm = P.cost + (size_t)m * P.cstride;
+    const uint8_t nv = patch[e];
+    const size_t ci = (size_t)cx * P.W + cy;
+    if (cm[ci] == nv) return;
+    cm[ci] = nv;
+    const int nn = NODES ? 4 : 1;
+    for (int k = 0; k < nn; ++k) {
+        const int ex = cx + (k & 1), ey = cy + (k >> 1);   // Cell::corners, Cell.cpp:48-60
+        const size_t el = (size_t)ex * P.EY + ey;
+        const unsigned int bit = 1u << (el & 31);
+        const unsigned int old = atomicOr(&P.mark[(size_t)m * P.mstride + (el >> 5)], bit);
+        if (!(old & bit)) atomicAdd(&P.num_updated[m], 1u);
+        const int gt = m * P.NTm + (ex / T) * P.TY + (ey / T);
+        if (atomicExch(&P.sflag[gt], 1) == 0) P.slist[atomicAdd(&P.ctr->scount, 1)] = gt;
+    }
+}
+__global__ void k_clear_marks(DevParams P, int m, int x, int y, int w, int h) {
+    // zero the bitmap words covering elements (x..x+h, y..y+w)
+    const int rows = h + 1;
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    const int r = e / (w + 1), c = e - r * (w + 1);
+    if (r >= rows) return;
+    const int ex = x + r, ey = y + c;
+    if (ex >= P.EX || ey >= P.EY) return;
+    const size_t el = (size_t)ex * P.EY + ey;
+    P.mark[(size_t)m * P.mstride + (el >> 5)] = 0u;
+}
+// pending seeds of consuming maps -> active list `buf`; others stay pending. One block.
+__global__ void k_seeds_to_active(DevParams P, int buf) {
+    __shared__ int s_keep;
+    if (threadIdx.x == 0) s_keep = 0;
+    __syncthreads();
+    const int n = P.ctr->scount;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        const int gt = P.slist[i];
+        if (P.consume[gt / P.NTm]) { P.sflag[gt] = 0; activate(P, buf, gt); }
+        else P.slist2[atomicAdd(&s_keep, 1)] = gt;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < s_keep; i += blockDim.x) P.slist[i] = P.slist2[i];
+    if (threadIdx.x == 0) P.ctr->scount = s_keep;
+}
+__global__ void k_touched_to_active(DevParams P, int buf) {
+    const int n = P.ctr->tcount;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) activate(P, buf, P.tlist[i]);
+}
+__global__ void k_activate_list(DevParams P, int buf, const int *tiles, int n) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) activate(P, buf, tiles[i]);
+}
+// count elements whose G differs from the snapshot taken at first touch; release the tiles
+__global__ __launch_bounds__(NTHR) void k_finalize(DevParams P) {
+    const int n = P.ctr->tcount;
+    const int io_r = threadIdx.x >> 5, io_c = threadIdx.x & 31;
+    for (int i = blockIdx.x; i < n; i += gridDim.x) {
+        const int gt = P.tlist[i];
+        const int m = gt / P.NTm, t = gt - m * P.NTm;
+        const int tx = t / P.TY, ty = t - tx * P.TY;
+        const size_t gidx = (size_t)m * P.gstride + (size_t)(tx * T + io_r + 1) * P.pitch + (ty * T + io_c + GPAD);
+        const int diff = P.G[gidx] != P.Gprev[gidx];
+        const int c = __syncthreads_count(diff);
+        if (threadIdx.x == 0) {
+            if (c) atomicAdd(&P.ctr->expanded, (unsigned long long)c);
+            P.touched[gt] = 0;
+        }
+    }
+}
+
+// ---- host side -------------------------------------------------------------------
+#define HIPCHK(expr)                                                      \
+    do {                                                                  \
+        hipError_t _e = (expr);                                           \
+        if (_e != hipSuccess) return UFM_ERR_HIP_BASE - (int)_e;          \
+    } while (0)
+
+struct PatchRect { int m, x, y, w, h; };
+
+struct MapState {
+    bool initialize_search = true;   // ReplannerBase.h:149
+    bool goal_set = false;           // :150
+    bool new_goal = false;           // :151
+    bool new_start = false;          // :152
+    bool have_map = false;           // !initialize_graph :148
+    float start_x = 0, start_y = 0, goal_x = 0, goal_y = 0;
+    int goal_ex = 0, goal_ey = 0;    // Node()/Cell() of the goal
+    bool goal_elem_valid = false;
+};
+
+struct Engine {
+    int algo = 0, opt_lvl = 0, heur = 0, device = 0, nmaps = 1;
+    float heuristic_multiplier = 1.0f;
+    int thr_uchar = 254;             // Graph.h:34
+    int W = 0, L = 0;
+    DevParams P{};
+    bool allocated = false;
+    hipStream_t stream = nullptr;
+    DevCounters *h_ctr = nullptr;    // pinned
+    int *h_scratch = nullptr;        // pinned, nmaps*4 ints
+    int *d_scratch = nullptr;
+    uint8_t *d_patch = nullptr;      // staging for host patches
+    size_t d_patch_cap = 0;
+    uint8_t *h_patch = nullptr;      // pinned staging
+    std::vector<MapState> maps;
+    std::vector<PatchRect> pending;
+    std::vector<uint64_t> upd_pending;   // per map
+    int buf = 0;
+    int grid_relax = 512;
+    int max_iters = 4 * T;
+    bool profiling = false;
+    std::vector<hipEvent_t> ev;
+    ufm_stats last{};
+
+    int alloc(int width, int length);
+    void release();
+    int launch_relax(int mode);
+    int run_phase(int mode, uint32_t *launches, float *kernel_ms);
+    int step(ufm_stats *out);
+    int patch(int m, const uint8_t *dev_patch, int x, int y, int w, int h);
+};
+
+void Engine::release() {
+    if (!allocated) return;
+    hipFree(P.G); hipFree(P.Gprev); hipFree(P.cost); hipFree(P.goal); hipFree(P.list); hipFree(P.flag);
+    hipFree(P.touched); hipFree(P.tlist); hipFree(P.sflag); hipFree(P.slist); hipFree(P.slist2);
+    hipFree(P.mark); hipFree(P.num_updated); hipFree(P.consume); hipFree(P.ctr);
+    hipFree(d_scratch);
+    allocated = false;
+}
+
+int Engine::alloc(int width, int length) {
+    release();
+    W = width; L = length;
+    const bool nodes = algo != UFM_ALGO_DFM;
+    P.W = W; P.L = L;
+    P.EX = nodes ? L + 1 : L;
+    P.EY = nodes ? W + 1 : W;
+    P.TX = (P.EX + T - 1) / T;
+    P.TY = (P.EY + T - 1) / T;
+    P.NTm = P.TX * P.TY;
+    P.nmaps = nmaps;
+    P.NT = P.NTm * nmaps;
+    P.pitch = P.TY * T + 2 * GPAD;
+    P.gstride = (size_t)(P.TX * T + 2) * P.pitch;
+    P.cstride = (size_t)L * W;
+    P.mstride = ((size_t)P.EX * P.EY + 31) / 32 + 1;
+    P.thr = thr_uchar;
+    const size_t gbytes = P.gstride * nmaps * sizeof(float);
+    HIPCHK(hipMalloc(&P.G, gbytes));
+    HIPCHK(hipMalloc(&P.Gprev, gbytes));
+    HIPCHK(hipMalloc(&P.cost, P.cstride * nmaps));
+    HIPCHK(hipMalloc(&P.goal, sizeof(int) * 2 * nmaps));
+    HIPCHK(hipMalloc(&P.list, sizeof(int) * 3 * P.NT));
+    HIPCHK(hipMalloc(&P.flag, sizeof(int) * 3 * P.NT));
+    HIPCHK(hipMalloc(&P.touched, sizeof(int) * P.NT));
+    HIPCHK(hipMalloc(&P.tlist, sizeof(int) * P.NT));
+    HIPCHK(hipMalloc(&P.sflag, sizeof(int) * P.NT));
+    HIPCHK(hipMalloc(&P.slist, sizeof(int) * P.NT));
+    HIPCHK(hipMalloc(&P.slist2, sizeof(int) * P.NT));
+    HIPCHK(hipMalloc(&P.mark, sizeof(unsigned int) * P.mstride * nmaps));
+    HIPCHK(hipMalloc(&P.num_updated, sizeof(unsigned int) * nmaps));
+    HIPCHK(hipMalloc(&P.consume, sizeof(int) * nmaps));
+    HIPCHK(hipMalloc(&P.ctr, sizeof(DevCounters)));
+    HIPCHK(hipMalloc(&d_scratch, sizeof(int) * 4 * nmaps));
+    allocated = true;
+    HIPCHK(hipMemsetAsync(P.flag, 0, sizeof(int) * 3 * P.NT, stream));
+    HIPCHK(hipMemsetAsync(P.touched, 0, sizeof(int) * P.NT, stream));
+    HIPCHK(hipMemsetAsync(P.sflag, 0, sizeof(int) * P.NT, stream));
+    HIPCHK(hipMemsetAsync(P.mark, 0, sizeof(unsigned int) * P.mstride * nmaps, stream));
+    HIPCHK(hipMemsetAsync(P.num_updated, 0, sizeof(unsigned int) * nmaps, stream));
+    HIPCHK(hipMemsetAsync(P.goal, 0xFF, sizeof(int) * 2 * nmaps, stream));
+    HIPCHK(hipMemsetAsync(P.ctr, 0, sizeof(DevCounters), stream));
+    k_fill<<<1024, 256, 0, stream>>>(P.G, P.gstride * nmaps, INFINITY);
+    k_fill<<<1024, 256, 0, stream>>>(P.Gprev, P.gstride * nmaps, INFINITY);
+    HIPCHK(hipGetLastError());
+    buf = 0;
+    pending.clear();
+    upd_pending.assign(nmaps, 0);
+    for (auto &ms : maps) { ms.have_map = false; ms.initialize_search = true; }
+    return UFM_OK;
+}
+
+int Engine::launch_relax(int mode) {
+    const dim3 g(grid_relax), b(NTHR);
+#define UFM_LAUNCH(A, M) k_relax<A, M><<<g, b, 0, stream>>>(P, buf, max_iters)
+    if (mode == MODE_LOWER) {
+        if (algo == UFM_ALGO_FD) UFM_LAUNCH(UFM_ALGO_FD, MODE_LOWER);
+        else if (algo == UFM_ALGO_SG) UFM_LAUNCH(UFM_ALGO_SG, MODE_LOWER);
+        else UFM_LAUNCH(UFM_ALGO_DFM, MODE_LOWER);
+    } else {
+        if (algo == UFM_ALGO_FD) UFM_LAUNCH(UFM_ALGO_FD, MODE_RAISE);
+        else if (algo == UFM_ALGO_SG) UFM_LAUNCH(UFM_ALGO_SG, MODE_RAISE);
+        else UFM_LAUNCH(UFM_ALGO_DFM, MODE_RAISE);
+    }
+#undef UFM_LAUNCH
+    buf = (buf + 1) % 3;
+    return UFM_OK;
+}
+
+// Launch relax kernels until the active list runs dry.  The list lengths live on
+// the device; the host peeks at them once per batch of launches (an empty launch
+// costs a few microseconds, a host round trip more).
+int Engine::run_phase(int mode, uint32_t *launches, float *kernel_ms) {
+    int batch = 4;
+    const long cap = 64L * (P.TX + P.TY) * T + 4096;   // generous bound on sweeps
+    long total = 0;
+    for (;;) {
+        for (int k = 0; k < batch; ++k) {
+            if (profiling) {
+                if (ev.size() < (size_t)(2 * (k + 1))) {
+                    hipEvent_t a, b2;
+                    HIPCHK(hipEventCreate(&a)); HIPCHK(hipEventCreate(&b2));
+                    ev.push_back(a); ev.push_back(b2);
+                }
+                HIPCHK(hipEventRecord(ev[2 * k], stream));
+            }
+            launch_relax(mode);
+            if (profiling) HIPCHK(hipEventRecord(ev[2 * k + 1], stream));
+        }
+        HIPCHK(hipGetLastError());
+        *launches += (uint32_t)batch;
+        total += batch;
+        HIPCHK(hipMemcpyAsync(h_ctr, P.ctr, sizeof(DevCounters), hipMemcpyDeviceToHost, stream));
+        HIPCHK(hipStreamSynchronize(stream));
+        if (profiling)
+            for (int k = 0; k < batch; ++k) {
+                float ms = 0;
+                HIPCHK(hipEventElapsedTime(&ms, ev[2 * k], ev[2 * k + 1]));
+                *kernel_ms += ms;
+            }
+        const int active = h_ctr->cnt[buf];
+        if (active == 0) return UFM_OK;
+        if (total > cap) return UFM_ERR_NOT_CONVERGED;
+        batch = active > 256 ? 16 : (active > 32 ? 8 : 4);
+    }
+}
+
+int Engine::patch(int m, const uint8_t *dev_patch, int x, int y, int w, int h) {
+    if (m < 0 || m >= nmaps || !allocated || !maps[m].have_map) return UFM_ERR_INVALID;
+    if (x < 0 || y < 0 || w <= 0 || h <= 0 || x + h > L || y + w > W) return UFM_ERR_INVALID;   // Graph.cpp:38-41
+    const int n = w * h;
+    if (algo == UFM_ALGO_DFM) k_patch<false><<<(n + 255) / 256, 256, 0, stream>>>(P, m, dev_patch, x, y, w, h);
+    else k_patch<true><<<(n + 255) / 256, 256, 0, stream>>>(P, m, dev_patch, x, y, w, h);
+    HIPCHK(hipGetLastError());
+    pending.push_back({m, x, y, w, h});
+    return UFM_OK;
+}
+
+int Engine::step(ufm_stats *out) {
+    // ReplannerBase.h:44-45
+    for (int m = 0; m < nmaps; ++m) if (!maps[m].have_map) return UFM_LOOP_FAILURE_NO_GRAPH;
+    for (int m = 0; m < nmaps; ++m) if (!maps[m].goal_set) return UFM_LOOP_FAILURE_NO_GOAL;
+    ufm_stats st{};
+    const auto t0 = std::chrono::steady_clock::now();
+
+    HIPCHK(hipMemsetAsync(P.ctr, 0, offsetof(DevCounters, scount), stream));                 // cnt[3], tcount
+    HIPCHK(hipMemsetAsync(&P.ctr->not_converged, 0, sizeof(DevCounters) - offsetof(DevCounters, not_converged), stream));
+    buf = 0;
+
+    // classify maps: (re)initialise, propagate pending patches, or idle  (ReplannerBase.h:48-59)
+    int n_init = 0, n_upd = 0;
+    int *consume = h_scratch, *init_tiles = h_scratch + nmaps, *goals = h_scratch + 2 * nmaps;
+    for (int m = 0; m < nmaps; ++m) {
+        MapState &ms = maps[m];
+        consume[m] = 0;
+        if (ms.initialize_search || ms.new_goal) {
+            consume[m] = 1;
+            goals[2 * m] = ms.goal_elem_valid ? ms.goal_ex : -1;
+            goals[2 * m + 1] = ms.goal_elem_valid ? ms.goal_ey : -1;
+            k_fill<<<1024, 256, 0, stream>>>(P.G + (size_t)m * P.gstride, P.gstride, INFINITY);
+            if (ms.goal_elem_valid) init_tiles[n_init++] = m * P.NTm + (ms.goal_ex / T) * P.TY + (ms.goal_ey / T);
+            else ++n_init;   // nothing reachable: field stays +inf
+        } else if (ms.new_start) {
+            ms.new_start = false;
+            consume[m] = 1;
+            ++n_upd;
+        }
+    }
+    // (goal array upload is per map to keep untouched maps' goals)
+    for (int m = 0; m < nmaps; ++m) {
+        MapState &ms = maps[m];
+        if (ms.initialize_search || ms.new_goal)
+            HIPCHK(hipMemcpyAsync(P.goal + 2 * m, goals + 2 * m, 2 * sizeof(int), hipMemcpyHostToDevice, stream));
+    }
+    uint64_t updated = 0;
+    bool have_seeds = false;
+    if (n_upd > 0 || n_init > 0) {
+        HIPCHK(hipMemcpyAsync(P.consume, consume, sizeof(int) * nmaps, hipMemcpyHostToDevice, stream));
+        // consume pending patch rectangles of the participating maps
+        std::vector<PatchRect> keep;
+        for (const PatchRect &r : pending) {
+            if (!consume[r.m]) { keep.push_back(r); continue; }
+            have_seeds = true;
+            const int cnt = (r.h + 1) * (r.w + 1);
+            k_clear_marks<<<(cnt + 255) / 256, 256, 0, stream>>>(P, r.m, r.x, r.y, r.w, r.h);
+        }
+        pending.swap(keep);
+    }
+    if (have_seeds) {
+        // num_nodes_updated (FD impl:138, DFM impl:109) of the participating maps
+        HIPCHK(hipMemcpyAsync(h_scratch + 2 * nmaps + 2 * nmaps, P.num_updated, sizeof(unsigned int) * nmaps, hipMemcpyDeviceToHost, stream));
+        k_seeds_to_active<<<1, 1024, 0, stream>>>(P, buf);
+        HIPCHK(hipStreamSynchronize(stream));
+        const unsigned int *nu = reinterpret_cast<const unsigned int *>(h_scratch + 4 * nmaps);
+        for (int m = 0; m < nmaps; ++m) {
+            MapState &ms = maps[m];
+            if (!consume[m]) continue;
+            if (!(ms.initialize_search || ms.new_goal)) updated += nu[m];
+            HIPCHK(hipMemsetAsync(P.num_updated + m, 0, sizeof(unsigned int), stream));
+        }
+    }
+    // invalidation phase: only needed when patches are being propagated into an existing field
+    if (have_seeds && n_upd > 0) {
+        int rc = run_phase(MODE_RAISE, &st.raise_launches, &st.kernel_ms);
+        if (rc != UFM_OK) return rc;
+        st.launches += st.raise_launches;
+        // everything the raise phase touched must be re-lowered
+        k_touched_to_active<<<64, 256, 0, stream>>>(P, buf);
+    }
+    if (n_init > 0) {
+        int k = 0;
+        for (int m = 0; m < nmaps; ++m) {
+            MapState &ms = maps[m];
+            if ((ms.initialize_search || ms.new_goal) && ms.goal_elem_valid) ++k;
+        }
+        if (k > 0) {
+            HIPCHK(hipMemcpyAsync(d_scratch, init_tiles, sizeof(int) * k, hipMemcpyHostToDevice, stream));
+            k_activate_list<<<1, 64, 0, stream>>>(P, buf, d_scratch, k);
+        }
+    }
+    HIPCHK(hipStreamSynchronize(stream));
+    const auto t1 = std::chrono::steady_clock::now();
+    st.u_ms = std::chrono::duration<float, std::milli>(t1 - t0).count();
+
+    // ReplannerBase.h:65-69: plan() only if something was (re)initialised or updated
+    const bool do_plan = n_init > 0 || updated > 0 || (have_seeds && n_upd > 0);
+    if (do_plan) {
+        uint32_t ll = 0;
+        int rc = run_phase(MODE_LOWER, &ll, &st.kernel_ms);
+        if (rc != UFM_OK) return rc;
+        st.launches += ll;
+        k_finalize<<<grid_relax, NTHR, 0, stream>>>(P);
+        HIPCHK(hipMemcpyAsync(h_ctr, P.ctr, sizeof(DevCounters), hipMemcpyDeviceToHost, stream));
+        HIPCHK(hipStreamSynchronize(stream));
+        st.expanded = h_ctr->expanded;
+        st.tile_visits = h_ctr->tile_visits;
+        st.tile_iters = h_ctr->tile_iters;
+        st.elem_evals = h_ctr->elem_evals;
+    }
+    for (int m = 0; m < nmaps; ++m) maps[m].new_goal = maps[m].initialize_search = false;
+    st.updated = updated;
+    const auto t2 = std::chrono::steady_clock::now();
+    st.p_ms = std::chrono::duration<float, std::milli>(t2 - t1).count();
+    last = st;
+    if (out) *out = st;
+    return UFM_OK;
+}
+
+int engine_create(Engine **out, int n_maps, int algo, int opt_lvl, int use_heuristic, int device_id) {
+    if (!out || n_maps < 1 || algo < 0 || algo > 2 || opt_lvl < 0 || opt_lvl > 2) return UFM_ERR_INVALID;
+    if (algo != UFM_ALGO_SG && opt_lvl > 1) return UFM_ERR_INVALID;   // only ShiftedGridPlanner has level 2
+    int ndev = 0;
+    HIPCHK(hipGetDeviceCount(&ndev));
+    if (device_id < 0 || device_id >= ndev) return UFM_ERR_INVALID;
+    HIPCHK(hipSetDevice(device_id));
+    Engine *e = new (std::nothrow) Engine();
+    if (!e) return UFM_ERR_NOMEM;
+    e->algo = algo; e->opt_lvl = opt_lvl; e->heur = use_heuristic; e->device = device_id; e->nmaps = n_maps;
+    e->maps.resize(n_maps);
+    hipDeviceProp_t prop;
+    HIPCHK(hipGetDeviceProperties(&prop, device_id));
+    e->grid_relax = prop.multiProcessorCount * 2;
+    HIPCHK(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
+    HIPCHK(hipHostMalloc(&e->h_ctr, sizeof(DevCounters)));
+    HIPCHK(hipHostMalloc(&e->h_scratch, sizeof(int) * 6 * n_maps));
+    *out = e;
+    return UFM_OK;
+}
+
+int engine_destroy(Engine *e) {
+    if (!e) return UFM_ERR_INVALID;
+    hipSetDevice(e->device);
+    if (e->stream) hipStreamSynchronize(e->stream);
+    e->release();
+    for (hipEvent_t v : e->ev) hipEventDestroy(v);
+    if (e->d_patch) hipFree(e->d_patch);
+    if (e->h_patch) hipHostFree(e->h_patch);
+    if (e->h_ctr) hipHostFree(e->h_ctr);
+    if (e->h_scratch) hipHostFree(e->h_scratch);
+    if (e->stream) hipStreamDestroy(e->stream);
+    delete e;
+    return UFM_OK;
+}
+
+int engine_set_map(Engine *e, int m, const uint8_t *src, bool on_device, int width, int length) {
+    if (!e || !src || m < 0 || m >= e->nmaps || width <= 0 || length <= 0) return UFM_ERR_INVALID;
+    HIPCHK(hipSetDevice(e->device));
+    if (!e->allocated || width != e->W || length != e->L) {
+        bool others = false;
+        for (int k = 0; k < e->nmaps; ++k) if (k != m && e->maps[k].have_map) others = true;
+        if (e->allocated && others) return UFM_ERR_INVALID;   // all maps of a batch share one size
+        int rc = e->alloc(width, length);
+        if (rc != UFM_OK) return rc;
+    }
+    HIPCHK(hipMemcpyAsync(e->P.cost + (size_t)m * e->P.cstride, src, (size_t)width * length,
+                          on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    e->maps[m].have_map = true;   // initialize_graph = false, ReplannerBase.h:87
+    // goal element validity depends on the map size
+    MapState &ms = e->maps[m];
+    if (ms.goal_set) ms.goal_elem_valid = ms.goal_ex >= 0 && ms.goal_ey >= 0 && ms.goal_ex < e->P.EX && ms.goal_ey < e->P.EY;
+    return UFM_OK;
+}
+
+int engine_patch(Engine *e, int m, const uint8_t *src, bool on_device, int x, int y, int w, int h) {
+    if (!e || !src) return UFM_ERR_INVALID;
+    HIPCHK(hipSetDevice(e->device));
+    if (on_device) return e->patch(m, src, x, y, w, h);
+    if (w <= 0 || h <= 0) return UFM_ERR_INVALID;
+    const size_t n = (size_t)w * h;
+    if (n > e->d_patch_cap) {
+        if (e->d_patch) { HIPCHK(hipStreamSynchronize(e->stream)); hipFree(e->d_patch); hipHostFree(e->h_patch); }
+        e->d_patch_cap = n < 4096 ? 4096 : n;
+        HIPCHK(hipMalloc(&e->d_patch, e->d_patch_cap));
+        HIPCHK(hipHostMalloc(&e->h_patch, e->d_patch_cap));
+    } else {
+        HIPCHK(hipStreamSynchronize(e->stream));   // staging buffers are reused
+    }
+    std::memcpy(e->h_patch, src, n);
+    HIPCHK(hipMemcpyAsync(e->d_patch, e->h_patch, n, hipMemcpyHostToDevice, e->stream));
+    return e->patch(m, e->d_patch, x, y, w, h);
+}
+
+int engine_set_goal(Engine *e, int m, float x, float y) {
+    if (!e || m < 0 || m >= e->nmaps) return UFM_ERR_INVALID;
+    MapState &ms = e->maps[m];
+    // Node(Position)/Cell(Position) round (Node.cpp:14-17, Cell.cpp:20-21); ReplannerBase.h:99-108
+    const int ex = (int)std::roundf(x), ey = (int)std::roundf(y);
+    ms.new_goal = !ms.goal_set ? true : (ex != ms.goal_ex || ey != ms.goal_ey);
+    ms.goal_x = x; ms.goal_y = y; ms.goal_ex = ex; ms.goal_ey = ey;
+    ms.goal_set = true;
+    ms.goal_elem_valid = e->allocated && ex >= 0 && ey >= 0 && ex < e->P.EX && ey < e->P.EY;
+    return UFM_OK;
+}
+
+int engine_read_field(Engine *e, int m, int x0, int y0, int nx, int ny, float *g, float *rhs) {
+    if (!e || m < 0 || m >= e->nmaps || !e->allocated) return UFM_ERR_INVALID;
+    if (x0 < 0 || y0 < 0 || nx <= 0 || ny <= 0 || x0 + nx > e->P.EX || y0 + ny > e->P.EY) return UFM_ERR_INVALID;
+    HIPCHK(hipSetDevice(e->device));
+    const float *src = e->P.G + (size_t)m * e->P.gstride + (size_t)(x0 + 1) * e->P.pitch + (y0 + GPAD);
+    float *dst = g ? g : rhs;
+    if (!dst) return UFM_OK;
+    HIPCHK(hipMemcpy2DAsync(dst, (size_t)ny * sizeof(float), src, (size_t)e->P.pitch * sizeof(float),
+                            (size_t)ny * sizeof(float), (size_t)nx, hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    // at the fixed point RHS(s) = F(G)(s) = G(s) for every element (goal: 0 = 0)
+    if (g && rhs) std::memcpy(rhs, g, (size_t)nx * ny * sizeof(float));
+    return UFM_OK;
+}
+
+}  // namespace
+
+// ---- C ABI ---------------------------------------------------------------------------
+struct ufm_planner { Engine *e; };
+struct ufm_batch { Engine *e; };
+
+extern "C" {
+
+const char *ufm_version(void) { return "ufm-gfx950 0.1 (block-FIM, tile 32)"; }
+
+int ufm_create(ufm_t **out, int algo, int opt_lvl, int use_heuristic, int device_id) {
+    if (!out) return UFM_ERR_INVALID;
+    Engine *e = nullptr;
+    int rc = engine_create(&e, 1, algo, opt_lvl, use_heuristic, device_id);
+    if (rc != UFM_OK) return rc;
+    *out = new ufm_planner{e};
+    return UFM_OK;
+}
+int ufm_destroy(ufm_t *p) {
+    if (!p) return UFM_ERR_INVALID;
+    int rc = engine_destroy(p->e);
+    delete p;
+    return rc;
+}
+int ufm_reset(ufm_t *p) { if (!p) return UFM_ERR_INVALID; p->e->maps[0].initialize_search = true; return UFM_OK; }
+int ufm_set_occupancy_threshold(ufm_t *p, float thr) {
+    if (!p) return UFM_ERR_INVALID;
+    p->e->thr_uchar = (int)(thr * 255.0f);   // Graph.cpp:18-20
+    p->e->P.thr = p->e->thr_uchar;
+    return UFM_OK;
+}
+int ufm_set_heuristic_multiplier(ufm_t *p, float mult) { if (!p) return UFM_ERR_INVALID; p->e->heuristic_multiplier = mult; return UFM_OK; }
+int ufm_set_map(ufm_t *p, const uint8_t *host_map, int width, int length) { return p ? engine_set_map(p->e, 0, host_map, false, width, length) : UFM_ERR_INVALID; }
+int ufm_set_map_device(ufm_t *p, const uint8_t *dev_map, int width, int length) { return p ? engine_set_map(p->e, 0, dev_map, true, width, length) : UFM_ERR_INVALID; }
+int ufm_patch_map(ufm_t *p, const uint8_t *host_patch, int x, int y, int w, int h) { return p ? engine_patch(p->e, 0, host_patch, false, x, y, w, h) : UFM_ERR_INVALID; }
+int ufm_patch_map_device(ufm_t *p, const uint8_t *dev_patch, int x, int y, int w, int h) { return p ? engine_patch(p->e, 0, dev_patch, true, x, y, w, h) : UFM_ERR_INVALID; }
+int ufm_set_start(ufm_t *p, float x, float y) {
+    if (!p) return UFM_ERR_INVALID;
+    MapState &ms = p->e->maps[0];
+    ms.start_x = x; ms.start_y = y; ms.new_start = true;   // ReplannerBase.h:94-97
+    return UFM_OK;
+}
+int ufm_set_goal(ufm_t *p, float x, float y) { return p ? engine_set_goal(p->e, 0, x, y) : UFM_ERR_INVALID; }
+int ufm_step(ufm_t *p, ufm_stats *stats) {
+    if (!p) return UFM_ERR_INVALID;
+    if (hipSetDevice(p->e->device) != hipSuccess) return UFM_ERR_HIP_BASE;
+    return p->e->step(stats);
+}
+int ufm_field_dims(const ufm_t *p, int *nx, int *ny) {
+    if (!p || !p->e->allocated) return UFM_ERR_INVALID;
+    if (nx) *nx = p->e->P.EX;
+    if (ny) *ny = p->e->P.EY;
+    return UFM_OK;
+}
+int ufm_read_field(ufm_t *p, int x0, int y0, int nx, int ny, float *g, float *rhs) { return p ? engine_read_field(p->e, 0, x0, y0, nx, ny, g, rhs) : UFM_ERR_INVALID; }
+int ufm_read_map(ufm_t *p, uint8_t *host_map) {
+    if (!p || !host_map || !p->e->allocated) return UFM_ERR_INVALID;
+    HIPCHK(hipSetDevice(p->e->device));
+    HIPCHK(hipMemcpyAsync(host_map, p->e->P.cost, p->e->P.cstride, hipMemcpyDeviceToHost, p->e->stream));
+    HIPCHK(hipStreamSynchronize(p->e->stream));
+    return UFM_OK;
+}
+int ufm_set_profiling(ufm_t *p, int enable) { if (!p) return UFM_ERR_INVALID; p->e->profiling = enable != 0; return UFM_OK; }
+void *ufm_stream(ufm_t *p) { return p ? (void *)p->e->stream : nullptr; }
+
+int ufm_batch_create(ufm_batch_t **out, int n_maps, int algo, int opt_lvl, int use_heuristic, int device_id) {
+    if (!out) return UFM_ERR_INVALID;
+    Engine *e = nullptr;
+    int rc = engine_create(&e, n_maps, algo, opt_lvl, use_heuristic, device_id);
+    if (rc != UFM_OK) return rc;
+    *out = new ufm_batch{e};
+    return UFM_OK;
+}
+int ufm_batch_destroy(ufm_batch_t *b) {
+    if (!b) return UFM_ERR_INVALID;
+    int rc = engine_destroy(b->e);
+    delete b;
+    return rc;
+}
+int ufm_batch_size(const ufm_batch_t *b) { return b ? b->e->nmaps : UFM_ERR_INVALID; }
+int ufm_batch_set_occupancy_threshold(ufm_batch_t *b, float thr) {
+    if (!b) return UFM_ERR_INVALID;
+    b->e->thr_uchar = (int)(thr * 255.0f);
+    b->e->P.thr = b->e->thr_uchar;
+    return UFM_OK;
+}
+int ufm_batch_set_map(ufm_batch_t *b, int i, const uint8_t *host_map, int width, int length) { return b ? engine_set_map(b->e, i, host_map, false, width, length) : UFM_ERR_INVALID; }
+int ufm_batch_patch_map(ufm_batch_t *b, int i, const uint8_t *host_patch, int x, int y, int w, int h) { return b ? engine_patch(b->e, i, host_patch, false, x, y, w, h) : UFM_ERR_INVALID; }
+int ufm_batch_set_start(ufm_batch_t *b, int i, float x, float y) {
+    if (!b || i < 0 || i >= b->e->nmaps) return UFM_ERR_INVALID;
+    MapState &ms = b->e->maps[i];
+    ms.start_x = x; ms.start_y = y; ms.new_start = true;
+    return UFM_OK;
+}
+int ufm_batch_set_goal(ufm_batch_t *b, int i, float x, float y) { return b ? engine_set_goal(b->e, i, x, y) : UFM_ERR_INVALID; }
+int ufm_batch_reset(ufm_batch_t *b, int i) {
+    if (!b || i < 0 || i >= b->e->nmaps) return UFM_ERR_INVALID;
+    b->e->maps[i].initialize_search = true;
+    return UFM_OK;
+}
+int ufm_batch_step(ufm_batch_t *b, ufm_stats *stats) {
+    if (!b) return UFM_ERR_INVALID;
+    if (hipSetDevice(b->e->device) != hipSuccess) return UFM_ERR_HIP_BASE;
+    return b->e->step(stats);
+}
+int ufm_batch_read_field(ufm_batch_t *b, int i, int x0, int y0, int nx, int ny, float *g, float *rhs) { return b ? engine_read_field(b->e, i, x0, y0, nx, ny, g, rhs) : UFM_ERR_INVALID; }
+
+}  // extern "C"
