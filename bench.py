@@ -1,0 +1,197 @@
+#!/usr/bin/env python3
+"""Headline benchmark (BASELINE.json): grid cells updated / second over a full
+plan + 100 replans on a 4096x4096 map, Field D* (level 1), per MI355X.
+
+One "step" = one episode = set the map, plan from scratch, then 100 x (apply a
+31x31 cost patch, move the start, replan).  Inputs (map, patches) are resident
+in HBM before the timed region.  With N > 1 every rank owns an independent map
+instance (weak scaling); the patch stream lives on rank 0 and reaches the other
+ranks by an RCCL broadcast before every replan (the only exchange the path has).
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+
+TILE = 32
+BYTES_PER_TILE_VISIT = 9 * TILE * TILE + (4 * TILE + 4) * 4   # 9 B/element + halo
+HBM_PEAK_GBS = 8000.0                                         # MI355X_MICROARCH.md: HBM3E peak
+
+
+def cpu_baseline(size, seed, n_patches):
+    """The oracle (a C port of the reference's D*-Lite FD-1 planner) timed on one host
+    core on a bounded sample of the same workload.  Checker/baseline only."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import oracle_py as orc
+    import ufm_amd
+    try:
+        os.sched_setaffinity(0, {sorted(os.sched_getaffinity(0))[0]})   # reference pins to one core (main.cpp:36-40)
+    except Exception:
+        pass
+    cost = ufm_amd.synth.cost_map(seed, size, size)
+    start, goal = ufm_amd.synth.start_goal(size, size)
+    p = orc.OraclePlanner(orc.ALGO_FD, 1, False)
+    p.reset(); p.set_occupancy_threshold(1); p.set_map(cost); p.set_start(*start); p.set_goal(*goal)
+    exp, ms = 0, 0.0
+    assert p.step() == 0
+    exp += p.num_expanded; ms += p.u_time + p.p_time
+    for k, s, top, left, patch in ufm_amd.synth.replan_script(seed, size, size, n_patches=n_patches):
+        p.patch_map(patch, top, left); p.set_start(*s)
+        assert p.step() == 0
+        exp += p.num_expanded; ms += p.u_time + p.p_time
+    return {"value": exp / (ms * 1e-3), "unit": "cells/s", "cores": 1, "kind": "port",
+            "sample": "FD-1 %dx%d seed %d, full plan + %d replans, %d expansions in %.1f s" % (
+                size, size, seed, n_patches, exp, ms * 1e-3)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--size", type=int, default=4096)
+    ap.add_argument("--patches", type=int, default=100)
+    ap.add_argument("--algo", default="FD", choices=["FD", "SG", "DFM"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-size", type=int, default=1024)
+    ap.add_argument("--no-profile", action="store_true", help="skip per-launch HIP event timing")
+    args = ap.parse_args()
+
+    import torch
+    import ufm_amd
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    else:
+        dist = None
+        torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    size, seed = args.size, 7
+    algo = {"FD": ufm_amd.ALGO_FD, "SG": ufm_amd.ALGO_SG, "DFM": ufm_amd.ALGO_DFM}[args.algo]
+    # independent map instance per rank; rank 0's instance is the BASELINE seed
+    cost = ufm_amd.synth.cost_map(seed + 1000 * rank, size, size)
+    start, goal = ufm_amd.synth.start_goal(size, size)
+    script = list(ufm_amd.synth.replan_script(seed, size, size, n_patches=args.patches))
+    d_cost = torch.from_numpy(cost).to(dev)
+    psz = script[0][4].shape[0] if script else 31
+    if rank == 0 and script:
+        d_patches = torch.from_numpy(np.stack([s[4] for s in script])).to(dev)
+    else:
+        d_patches = torch.empty((max(1, len(script)), psz, psz), dtype=torch.uint8, device=dev)
+    d_recv = torch.empty((psz, psz), dtype=torch.uint8, device=dev)
+
+    planner = ufm_amd.Planner(algo, 1 if algo != ufm_amd.ALGO_SG else 2, False, device=local_rank)
+    planner.set_occupancy_threshold(1)
+    planner.set_profiling(not args.no_profile)
+
+    def episode():
+        cells = visits = launches = evals = 0
+        kms = 0.0
+        planner.set_map_device(d_cost.data_ptr(), size, size)
+        planner.reset()
+        planner.set_start(*start)
+        planner.set_goal(*goal)
+        assert planner.step() == 0
+        st = planner.stats
+        cells += st.expanded; visits += st.tile_visits; launches += st.launches; kms += st.kernel_ms; evals += st.elem_evals
+        for i, (k, s, top, left, _) in enumerate(script):
+            if dist is not None:
+                if rank == 0:
+                    d_recv.copy_(d_patches[i])
+                dist.broadcast(d_recv, src=0)
+                torch.cuda.current_stream().synchronize()
+                src = d_recv
+            else:
+                src = d_patches[i]
+            planner.patch_map_device(src.data_ptr(), top, left, psz, psz)
+            planner.set_start(*s)
+            assert planner.step() == 0
+            st = planner.stats
+            cells += st.expanded; visits += st.tile_visits; launches += st.launches; kms += st.kernel_ms; evals += st.elem_evals
+        return cells, visits, launches, kms, evals
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        episode()
+    barrier()
+    t0 = time.perf_counter()
+    tot = [0, 0, 0, 0.0, 0]
+    for _ in range(args.steps):
+        r = episode()
+        tot = [a + b for a, b in zip(tot, r)]
+    barrier()
+    dt = time.perf_counter() - t0
+
+    cells, visits, launches, kms, evals = tot
+    if dist is not None:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+        c = torch.tensor([cells, visits, launches, evals], dtype=torch.float64, device=dev)
+        dist.all_reduce(c, op=dist.ReduceOp.SUM)
+        cells_all = float(c[0].item())
+    else:
+        cells_all = float(cells)
+
+    if rank == 0:
+        out = {
+            "metric": "grid cells updated/sec (full plan + 100 replans), 4096^2 map",
+            "value": cells_all / dt,
+            "unit": "cells/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": 1e3 * dt / max(1, args.steps),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {
+                "workload": "Field D* level-1, %dx%d cost map (seed 7 generator, SURVEY 8d), full plan + %d 31x31 patches with moving start, one map instance per GPU" % (size, size, len(script)),
+                "algo": args.algo, "size": size, "patches": len(script),
+                "cells_per_step_rank0": cells / max(1, args.steps),
+                "relax_launches_per_step_rank0": launches / max(1, args.steps),
+                "tile_visits_per_step_rank0": visits / max(1, args.steps),
+                "elem_evals_per_step_rank0": evals / max(1, args.steps),
+            },
+        }
+        if kms > 0 and launches > 0:
+            achieved = visits * BYTES_PER_TILE_VISIT / (kms * 1e-3) / 1e9
+            out["roofline"] = {
+                "bound": "hbm", "kernel": "k_relax", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                "avg_launch_us": 1e3 * kms / launches,
+                "algorithmic_bytes_per_launch": visits * BYTES_PER_TILE_VISIT / launches,
+                "kernel_time_share": kms * 1e-3 / dt,
+            }
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args.cpu_size, seed, args.patches)
+        print(json.dumps(out))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

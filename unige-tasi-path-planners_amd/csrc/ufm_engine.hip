@@ -87,10 +87,24 @@ __device__ __forceinline__ void activate(const DevParams &P, int nb, int gt) {
 }
 
 // ---- update operators -------------------------------------------------------
+// Correctly rounded fp32 square root (std::sqrt of the reference, Macros.h:12):
+// v_sqrt_f32 is good to 1 ulp; two fused residuals pick the neighbour that is
+// the round-to-nearest result.  Arguments here are never denormal, so the
+// scaling steps of the generic library routine are omitted.
+__device__ __forceinline__ float sqrt_rn(float x) {
+    float s = __builtin_amdgcn_sqrtf(x);
+    const float sm = __int_as_float(__float_as_int(s) - 1);
+    const float sp = __int_as_float(__float_as_int(s) + 1);
+    const float rm = __builtin_fmaf(-sm, s, x);
+    const float rp = __builtin_fmaf(-sp, s, x);
+    s = (rm <= 0.0f) ? sm : s;
+    s = (rp > 0.0f) ? sp : s;
+    return s;
+}
 // ShiftedGridPlanner_impl.h:422-436 (+ InterpolatedTraversal.cpp:125-127,324-326,403-405)
 __device__ __forceinline__ float tri_sg(float g1, float g2, float c) {
     const float f = g1 - g2;
-    const float tII = g1 + __fsqrt_rn(c * c - f * f);
+    const float tII = g1 + sqrt_rn(c * c - f * f);
     const float tA = g2 + c * SQRT2F;
     float r = (f * SQRT2F <= c) ? tII : tA;
     r = (f <= 0.0f) ? (g1 + c) : r;
@@ -100,7 +114,7 @@ __device__ __forceinline__ float tri_sg(float g1, float g2, float c) {
 // cb = CATH(c,b) is constant during a tile visit and passed in.
 __device__ __forceinline__ float tri_fd(float g1, float g2, float b, float c, float cb) {
     const float f = g1 - g2;
-    const float tII = g1 + __fsqrt_rn(c * c - f * f);
+    const float tII = g1 + sqrt_rn(c * c - f * f);
     const float tA = g2 + c * SQRT2F;
     const bool cIII = (f <= 0.0f) || (f * f <= cb);
     const bool cII = (f <= b) && (c > f * SQRT2F);
@@ -115,7 +129,7 @@ __device__ __forceinline__ float tri_fd(float g1, float g2, float b, float c, fl
 __device__ __forceinline__ float q_dfm(float a, float b, float th) {
     const float ga = fminf(a, b), gb = fmaxf(a, b);
     const float d = gb - ga;
-    const float s = ((ga + gb) + __fsqrt_rn(2.0f * (th * th) - d * d)) * 0.5f;
+    const float s = ((ga + gb) + sqrt_rn(2.0f * (th * th) - d * d)) * 0.5f;
     return (th > d) ? s : (ga + th);        // both inf -> d NaN -> ga + th = inf
 }
 
@@ -230,45 +244,56 @@ __global__ __launch_bounds__(NTHR) void k_relax(DevParams P, int buf, int max_it
             C.c11 = Cs[(lx + 1) * CP + ly + 1];
         }
         if (ALGO == UFM_ALGO_FD) {   // CATH(c,b), Macros.h:12, per (c,b) pair of eval_elem
-            C.k0 = __fsqrt_rn(C.c00 * C.c00 - C.c01 * C.c01);
-            C.k1 = __fsqrt_rn(C.c00 * C.c00 - C.c10 * C.c10);
-            C.k2 = __fsqrt_rn(C.c01 * C.c01 - C.c00 * C.c00);
-            C.k3 = __fsqrt_rn(C.c01 * C.c01 - C.c11 * C.c11);
-            C.k4 = __fsqrt_rn(C.c10 * C.c10 - C.c11 * C.c11);
-            C.k5 = __fsqrt_rn(C.c10 * C.c10 - C.c00 * C.c00);
-            C.k6 = __fsqrt_rn(C.c11 * C.c11 - C.c10 * C.c10);
-            C.k7 = __fsqrt_rn(C.c11 * C.c11 - C.c01 * C.c01);
+            C.k0 = sqrt_rn(C.c00 * C.c00 - C.c01 * C.c01);
+            C.k1 = sqrt_rn(C.c00 * C.c00 - C.c10 * C.c10);
+            C.k2 = sqrt_rn(C.c01 * C.c01 - C.c00 * C.c00);
+            C.k3 = sqrt_rn(C.c01 * C.c01 - C.c11 * C.c11);
+            C.k4 = sqrt_rn(C.c10 * C.c10 - C.c11 * C.c11);
+            C.k5 = sqrt_rn(C.c10 * C.c10 - C.c00 * C.c00);
+            C.k6 = sqrt_rn(C.c11 * C.c11 - C.c10 * C.c10);
+            C.k7 = sqrt_rn(C.c11 * C.c11 - C.c01 * C.c01);
         }
         const bool is_goal = (x0 + lx == P.goal[2 * m]) && (y0 + ly == P.goal[2 * m + 1]);
 
         int cur = 0, it = 0, wave_evals = 0;
         bool conv = false;
+        // Increases in the lowering phase are ulp-level corrections of values that were
+        // computed from transient neighbours.  Two neighbours that feed each other can
+        // flip-flop forever if they rise in the same sweep, so an element may only rise
+        // in sweeps of its own colour (4-colouring: no two 8-neighbours share one).
+        const int colour = (lx & 1) | ((ly & 1) << 1);
         for (; it < max_iters; ++it) {
-            int changed = 0;
+            int want = 0;
             if (s_dirty[cur][w]) {                       // wave-uniform
                 if (lane == 0) s_dirty[cur][w] = 0;
                 float nv = eval_elem<ALGO>(Gs, lx, ly, C);
                 if (is_goal) nv = 0.0f;                  // RHS(goal) = 0, *_impl.h init()
+                int doit;
                 if (MODE == MODE_LOWER) {
-                    changed = (nv != g);                 // replace semantics: G <- F(G)
+                    want = (nv != g);                    // replace semantics: G <- F(G)
+                    doit = want && ((nv < g) || (colour == (it & 3)));
                 } else {
-                    changed = (g < INFINITY) && (nv > g);   // value lost its support
+                    want = (g < INFINITY) && (nv > g);   // value lost its support
+                    doit = want;
                     nv = INFINITY;
                 }
-                if (changed) { g = nv; Gs[(lx + 1) * GP + ly + 1] = nv; }
-                const unsigned long long mask = __ballot(changed);
-                if (mask && lane < 9) {                  // wake the patches whose inputs changed
+                if (doit) { g = nv; Gs[(lx + 1) * GP + ly + 1] = nv; }
+                const unsigned long long mask = __ballot(doit);
+                const unsigned long long deferred = __ballot(want && !doit);
+                if ((mask | deferred) && lane < 9) {     // wake the patches whose inputs changed
                     const int dr = lane / 3 - 1, dc = lane % 3 - 1;
                     unsigned long long sel = ~0ull;
                     if (dr < 0) sel &= 0x00000000000000FFull; else if (dr > 0) sel &= 0xFF00000000000000ull;
                     if (dc < 0) sel &= 0x0101010101010101ull; else if (dc > 0) sel &= 0x8080808080808080ull;
                     const int pr = (w >> 2) + dr, pc = (w & 3) + dc;
-                    if ((mask & sel) && pr >= 0 && pr < 4 && pc >= 0 && pc < 4) s_dirty[cur ^ 1][pr * 4 + pc] = 1;
+                    const bool self = (dr == 0) && (dc == 0);
+                    if (((mask & sel) || (self && deferred)) && pr >= 0 && pr < 4 && pc >= 0 && pc < 4)
+                        s_dirty[cur ^ 1][pr * 4 + pc] = 1;
                 }
                 ++wave_evals;
             }
             cur ^= 1;
-            if (!__syncthreads_or(changed)) { conv = true; ++it; break; }
+            if (!__syncthreads_or(want)) { conv = true; ++it; break; }
         }
         if (lane == 0 && wave_evals) atomicAdd(&s_misc[2], wave_evals);
 
