@@ -90,6 +90,13 @@ int ufm_read_field(ufm_t *p, int x0, int y0, int nx, int ny, float *g, float *rh
 /* current raster (after patches), row-major [length][width] */
 int ufm_read_map(ufm_t *p, uint8_t *host_map);
 
+/* ---- tuning knobs of the tile scheduler (no reference counterpart; results do not depend
+ * on them).  "delta": absolute width of the ordering band in cost units (< 0: automatic);
+ * "delta_scale": band = scale * tile edge * mean traversable cost (default 1);
+ * "max_iters": in-LDS sweep cap per tile visit; "batch": relax launches per host check
+ * (0: adaptive); "grid": workgroups per relax launch. ---- */
+int ufm_set_param(ufm_t *p, const char *name, double value);
+
 /* ---- measurement hooks ---- */
 int ufm_set_profiling(ufm_t *p, int enable);   /* HIP-event timing of every relax launch */
 void *ufm_stream(ufm_t *p);                    /* hipStream_t the kernels run on */

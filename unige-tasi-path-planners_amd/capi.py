@@ -16,7 +16,7 @@ SYMBOLS = [
     "ufm_create", "ufm_destroy", "ufm_reset", "ufm_set_occupancy_threshold",
     "ufm_set_heuristic_multiplier", "ufm_set_map", "ufm_patch_map", "ufm_set_start",
     "ufm_set_goal", "ufm_step", "ufm_set_map_device", "ufm_patch_map_device",
-    "ufm_field_dims", "ufm_read_field", "ufm_read_map", "ufm_set_profiling", "ufm_stream",
+    "ufm_field_dims", "ufm_read_field", "ufm_read_map", "ufm_set_param", "ufm_set_profiling", "ufm_stream",
     "ufm_version", "ufm_batch_create", "ufm_batch_destroy", "ufm_batch_size",
     "ufm_batch_set_occupancy_threshold", "ufm_batch_set_map", "ufm_batch_patch_map",
     "ufm_batch_set_start", "ufm_batch_set_goal", "ufm_batch_reset", "ufm_batch_step",
@@ -75,6 +75,7 @@ def load_library():
     L.ufm_field_dims.argtypes = [vp, C.POINTER(i), C.POINTER(i)]
     L.ufm_read_field.argtypes = [vp, i, i, i, i, vp, vp]
     L.ufm_read_map.argtypes = [vp, vp]
+    L.ufm_set_param.argtypes = [vp, C.c_char_p, C.c_double]
     L.ufm_set_profiling.argtypes = [vp, i]
     L.ufm_stream.argtypes = [vp]
     L.ufm_stream.restype = vp
@@ -159,6 +160,9 @@ class Planner:
 
     def set_goal(self, x, y):
         _chk(self.L.ufm_set_goal(self.h, float(x), float(y)), "ufm_set_goal")
+
+    def set_param(self, name, value):
+        _chk(self.L.ufm_set_param(self.h, name.encode(), float(value)), "ufm_set_param")
 
     def set_profiling(self, on):
         _chk(self.L.ufm_set_profiling(self.h, int(on)), "ufm_set_profiling")

@@ -42,11 +42,14 @@ constexpr float SQRT2F = 1.41421356237309504880168872420969807856967187537694f; 
 
 enum { MODE_LOWER = 0, MODE_RAISE = 1 };
 
+constexpr int INFBITS = 0x7F800000;   // +inf as int: non-negative floats order like their bits
+
 struct DevCounters {
-    int cnt[3];                 // active-list lengths (ring of three)
+    int ncand[2];               // candidate-list lengths (double buffer)
+    int nready;                 // tiles released by the last triage
     int tcount;                 // touched-list length
-    int scount;                 // pending-seed-list length
-    int not_converged;
+    int scount;                 // pending-seed-list length (survives steps)
+    int pad0;
     unsigned long long expanded;
     unsigned long long tile_visits;
     unsigned long long tile_iters;
@@ -58,8 +61,10 @@ struct DevParams {
     float *Gprev;               // snapshot of a tile at its first touch in a step
     uint8_t *cost;              // [nmaps][L][W]
     int *goal;                  // [nmaps][2]
-    int *list;                  // [3][NT] active tiles (global tile ids)
-    int *flag;                  // [3][NT]
+    int *cand;                  // [2][NT] queued tiles (global tile ids), double buffer
+    int *ready;                 // [NT] tiles released for the current relax launch
+    int *queued;                // [NT] tile is in a candidate list
+    int *prio;                  // [NT] float bits: smallest value that entered the tile since its last visit
     int *touched;               // [NT]
     int *tlist;                 // [NT]
     int *sflag;                 // [NT] pending seeds (from patches)
@@ -79,10 +84,11 @@ struct DevParams {
     size_t mstride;             // words per map in mark
 };
 
-__device__ __forceinline__ void activate(const DevParams &P, int nb, int gt) {
-    if (atomicExch(&P.flag[nb * P.NT + gt], 1) == 0) {
-        const int k = atomicAdd(&P.ctr->cnt[nb], 1);
-        P.list[nb * P.NT + k] = gt;
+__device__ __forceinline__ void activate(const DevParams &P, int nb, int gt, int pbits) {
+    atomicMin(&P.prio[gt], pbits);
+    if (atomicExch(&P.queued[gt], 1) == 0) {
+        const int k = atomicAdd(&P.ctr->ncand[nb], 1);
+        P.cand[nb * P.NT + k] = gt;
     }
 }
 
@@ -183,23 +189,22 @@ __device__ __forceinline__ float cell_cost(const DevParams &P, const uint8_t *cm
 
 // ---- the hot kernel: one workgroup relaxes one active tile at a time ----------
 template <int ALGO, int MODE>
-__global__ __launch_bounds__(NTHR) void k_relax(DevParams P, int buf, int max_iters) {
+__global__ __launch_bounds__(NTHR) void k_relax(DevParams P, int nb, int max_iters) {
     __shared__ float Gs[(T + 2) * GP];
     __shared__ float Cs[(T + 1) * CP];
     __shared__ int s_dirty[2][16];
-    __shared__ int s_misc[4];   // 0: first touch, 1: border-change mask, 2: wave evaluations
+    __shared__ int s_misc[4];   // 0: first touch, 2: wave evaluations
+    __shared__ int s_bmin[9];   // per direction: smallest changed value on that border (float bits)
 
     const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
     const int lx = (w >> 2) * 8 + (lane >> 3), ly = (w & 3) * 8 + (lane & 7);   // compute mapping
     const int io_r = tid >> 5, io_c = tid & 31;                                 // HBM mapping
-    const int nb = (buf + 1) % 3;
-    const int n = P.ctr->cnt[buf];
-    if (blockIdx.x == 0 && tid == 0) P.ctr->cnt[(buf + 2) % 3] = 0;
+    const int n = P.ctr->nready;
     constexpr int CROWS = (ALGO == UFM_ALGO_DFM) ? T : T + 1;
     constexpr int COFF = (ALGO == UFM_ALGO_DFM) ? 0 : 1;
 
     for (int i = blockIdx.x; i < n; i += gridDim.x) {
-        const int gt = P.list[buf * P.NT + i];
+        const int gt = P.ready[i];
         const int m = gt / P.NTm, t = gt - m * P.NTm;
         const int tx = t / P.TY, ty = t - tx * P.TY;
         const int x0 = tx * T, y0 = ty * T;
@@ -207,12 +212,12 @@ __global__ __launch_bounds__(NTHR) void k_relax(DevParams P, int buf, int max_it
         const uint8_t *cm = P.cost + (size_t)m * P.cstride;
 
         if (tid == 0) {
-            P.flag[buf * P.NT + gt] = 0;
             const int first = atomicExch(&P.touched[gt], 1) == 0;
             if (first) P.tlist[atomicAdd(&P.ctr->tcount, 1)] = gt;
-            s_misc[0] = first; s_misc[1] = 0; s_misc[2] = 0;
+            s_misc[0] = first; s_misc[2] = 0;
         }
         if (tid < 16) { s_dirty[0][tid] = 1; s_dirty[1][tid] = 0; }
+        if (tid >= 32 && tid < 41) s_bmin[tid - 32] = INFBITS;
 
         // stage G tile + halo (rows padded by one, columns by GPAD: no bounds checks)
         const size_t gidx = (size_t)(x0 + io_r + 1) * P.pitch + (y0 + io_c + GPAD);
@@ -301,25 +306,26 @@ __global__ __launch_bounds__(NTHR) void k_relax(DevParams P, int buf, int max_it
         const float gf = Gs[(io_r + 1) * GP + io_c + 1];
         if (gf != gl0) {
             Gm[gidx] = gf;
+            // priority handed to a neighbour: the new value (lowering); invalidations are unordered
+            const int pb = (MODE == MODE_LOWER) ? __float_as_int(gf) : 0;
             const int er = (io_r == 0) ? -1 : ((io_r == T - 1) ? 1 : 0);
             const int ec = (io_c == 0) ? -1 : ((io_c == T - 1) ? 1 : 0);
-            int bits = 0;
-            if (er) bits |= 1 << ((er + 1) * 3 + 1);
-            if (ec) bits |= 1 << (3 + ec + 1);
-            if (er && ec) bits |= 1 << ((er + 1) * 3 + ec + 1);
-            if (bits) atomicOr(&s_misc[1], bits);
+            if (!conv) atomicMin(&s_bmin[4], pb);
+            if (er) atomicMin(&s_bmin[(er + 1) * 3 + 1], pb);
+            if (ec) atomicMin(&s_bmin[3 + ec + 1], pb);
+            if (er && ec) atomicMin(&s_bmin[(er + 1) * 3 + ec + 1], pb);
         }
         __syncthreads();
         if (tid < 9) {
             const int dr = tid / 3 - 1, dc = tid % 3 - 1;
             if (tid == 4) {
-                if (!conv) activate(P, nb, gt);          // sweep cap hit: come back
+                if (!conv) activate(P, nb, gt, min(s_bmin[4], INFBITS - 1));   // sweep cap hit: come back
                 atomicAdd(&P.ctr->tile_visits, 1ull);
                 atomicAdd(&P.ctr->tile_iters, (unsigned long long)it);
                 atomicAdd(&P.ctr->elem_evals, 64ull * (unsigned long long)s_misc[2]);
-            } else if (s_misc[1] & (1 << tid)) {
+            } else if (s_bmin[tid] != INFBITS) {
                 const int ntx = tx + dr, nty = ty + dc;
-                if (ntx >= 0 && ntx < P.TX && nty >= 0 && nty < P.TY) activate(P, nb, m * P.NTm + ntx * P.TY + nty);
+                if (ntx >= 0 && ntx < P.TX && nty >= 0 && nty < P.TY) activate(P, nb, m * P.NTm + ntx * P.TY + nty, s_bmin[tid]);
             }
         }
         __syncthreads();
@@ -374,7 +380,7 @@ __global__ void k_seeds_to_active(DevParams P, int buf) {
     const int n = P.ctr->scount;
     for (int i = threadIdx.x; i < n; i += blockDim.x) {
         const int gt = P.slist[i];
-        if (P.consume[gt / P.NTm]) { P.sflag[gt] = 0; activate(P, buf, gt); }
+        if (P.consume[gt / P.NTm]) { P.sflag[gt] = 0; activate(P, buf, gt, 0); }
         else P.slist2[atomicAdd(&s_keep, 1)] = gt;
     }
     __syncthreads();
@@ -383,10 +389,46 @@ __global__ void k_seeds_to_active(DevParams P, int buf) {
 }
 __global__ void k_touched_to_active(DevParams P, int buf) {
     const int n = P.ctr->tcount;
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) activate(P, buf, P.tlist[i]);
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) activate(P, buf, P.tlist[i], 0);
 }
 __global__ void k_activate_list(DevParams P, int buf, const int *tiles, int n) {
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) activate(P, buf, tiles[i]);
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) activate(P, buf, tiles[i], 0);
+}
+// Tile-level ordering (block fast marching): of the queued tiles only those whose incoming
+// value is within `delta` of the smallest one are released to the next relax launch; the rest
+// wait (their inputs are still going to improve).  delta = +inf degenerates to plain FIM.
+// One workgroup; also recycles the list counters.
+__global__ __launch_bounds__(1024) void k_triage(DevParams P, int cur, float delta) {
+    __shared__ int s_min;
+    const int nb = cur ^ 1;
+    const int n = P.ctr->ncand[cur];
+    if (threadIdx.x == 0) { P.ctr->nready = 0; P.ctr->ncand[nb] = 0; s_min = INFBITS; }
+    __syncthreads();
+    int lmin = INFBITS;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) lmin = min(lmin, P.prio[P.cand[cur * P.NT + i]]);
+    if (lmin != INFBITS) atomicMin(&s_min, lmin);
+    __syncthreads();
+    const float theta = __int_as_float(s_min) + delta;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        const int gt = P.cand[cur * P.NT + i];
+        if (!(__int_as_float(P.prio[gt]) > theta)) {
+            P.ready[atomicAdd(&P.ctr->nready, 1)] = gt;
+            P.queued[gt] = 0;
+            P.prio[gt] = INFBITS;
+        } else {
+            P.cand[nb * P.NT + atomicAdd(&P.ctr->ncand[nb], 1)] = gt;
+        }
+    }
+}
+// mean traversable cost of a raster (sets the default ordering band)
+__global__ void k_cost_stats(const uint8_t *cm, size_t n, int thr, unsigned long long *out) {
+    unsigned long long s = 0, c = 0;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const int v = cm[i];
+        if (v < thr) { s += v; ++c; }
+    }
+    for (int o = 32; o > 0; o >>= 1) { s += __shfl_down(s, o); c += __shfl_down(c, o); }
+    if ((threadIdx.x & 63) == 0) { atomicAdd(&out[0], s); atomicAdd(&out[1], c); }
 }
 // count elements whose G differs from the snapshot taken at first touch; release the tiles
 __global__ __launch_bounds__(NTHR) void k_finalize(DevParams P) {
@@ -443,9 +485,13 @@ struct Engine {
     std::vector<MapState> maps;
     std::vector<PatchRect> pending;
     std::vector<uint64_t> upd_pending;   // per map
-    int buf = 0;
+    int buf = 0;                     // candidate list the next triage reads
     int grid_relax = 512;
     int max_iters = 4 * T;
+    float delta_abs = -1.0f;         // ordering band; < 0: delta_scale * T * mean traversable cost
+    float delta_scale = 1.0f;
+    float mean_cost = 1.0f;
+    int batch_fixed = 0;
     bool profiling = false;
     std::vector<hipEvent_t> ev;
     ufm_stats last{};
@@ -460,7 +506,7 @@ struct Engine {
 
 void Engine::release() {
     if (!allocated) return;
-    hipFree(P.G); hipFree(P.Gprev); hipFree(P.cost); hipFree(P.goal); hipFree(P.list); hipFree(P.flag);
+    hipFree(P.G); hipFree(P.Gprev); hipFree(P.cost); hipFree(P.goal); hipFree(P.cand); hipFree(P.ready); hipFree(P.queued); hipFree(P.prio);
     hipFree(P.touched); hipFree(P.tlist); hipFree(P.sflag); hipFree(P.slist); hipFree(P.slist2);
     hipFree(P.mark); hipFree(P.num_updated); hipFree(P.consume); hipFree(P.ctr);
     hipFree(d_scratch);
@@ -489,8 +535,10 @@ int Engine::alloc(int width, int length) {
     HIPCHK(hipMalloc(&P.Gprev, gbytes));
     HIPCHK(hipMalloc(&P.cost, P.cstride * nmaps));
     HIPCHK(hipMalloc(&P.goal, sizeof(int) * 2 * nmaps));
-    HIPCHK(hipMalloc(&P.list, sizeof(int) * 3 * P.NT));
-    HIPCHK(hipMalloc(&P.flag, sizeof(int) * 3 * P.NT));
+    HIPCHK(hipMalloc(&P.cand, sizeof(int) * 2 * P.NT));
+    HIPCHK(hipMalloc(&P.ready, sizeof(int) * P.NT));
+    HIPCHK(hipMalloc(&P.queued, sizeof(int) * P.NT));
+    HIPCHK(hipMalloc(&P.prio, sizeof(int) * P.NT));
     HIPCHK(hipMalloc(&P.touched, sizeof(int) * P.NT));
     HIPCHK(hipMalloc(&P.tlist, sizeof(int) * P.NT));
     HIPCHK(hipMalloc(&P.sflag, sizeof(int) * P.NT));
@@ -500,9 +548,10 @@ int Engine::alloc(int width, int length) {
     HIPCHK(hipMalloc(&P.num_updated, sizeof(unsigned int) * nmaps));
     HIPCHK(hipMalloc(&P.consume, sizeof(int) * nmaps));
     HIPCHK(hipMalloc(&P.ctr, sizeof(DevCounters)));
-    HIPCHK(hipMalloc(&d_scratch, sizeof(int) * 4 * nmaps));
+    HIPCHK(hipMalloc(&d_scratch, sizeof(int) * (4 * nmaps + 4)));
     allocated = true;
-    HIPCHK(hipMemsetAsync(P.flag, 0, sizeof(int) * 3 * P.NT, stream));
+    HIPCHK(hipMemsetAsync(P.queued, 0, sizeof(int) * P.NT, stream));
+    k_fill<<<64, 256, 0, stream>>>(reinterpret_cast<float *>(P.prio), (size_t)P.NT, INFINITY);
     HIPCHK(hipMemsetAsync(P.touched, 0, sizeof(int) * P.NT, stream));
     HIPCHK(hipMemsetAsync(P.sflag, 0, sizeof(int) * P.NT, stream));
     HIPCHK(hipMemsetAsync(P.mark, 0, sizeof(unsigned int) * P.mstride * nmaps, stream));
@@ -521,7 +570,10 @@ int Engine::alloc(int width, int length) {
 
 int Engine::launch_relax(int mode) {
     const dim3 g(grid_relax), b(NTHR);
-#define UFM_LAUNCH(A, M) k_relax<A, M><<<g, b, 0, stream>>>(P, buf, max_iters)
+    // invalidation is order-free; lowering releases tiles in bands of `delta`
+    const float delta = (mode == MODE_RAISE) ? INFINITY : (delta_abs >= 0.0f ? delta_abs : delta_scale * T * mean_cost);
+    k_triage<<<1, 1024, 0, stream>>>(P, buf, delta);
+#define UFM_LAUNCH(A, M) k_relax<A, M><<<g, b, 0, stream>>>(P, buf ^ 1, max_iters)
     if (mode == MODE_LOWER) {
         if (algo == UFM_ALGO_FD) UFM_LAUNCH(UFM_ALGO_FD, MODE_LOWER);
         else if (algo == UFM_ALGO_SG) UFM_LAUNCH(UFM_ALGO_SG, MODE_LOWER);
@@ -532,7 +584,7 @@ int Engine::launch_relax(int mode) {
         else UFM_LAUNCH(UFM_ALGO_DFM, MODE_RAISE);
     }
 #undef UFM_LAUNCH
-    buf = (buf + 1) % 3;
+    buf ^= 1;
     return UFM_OK;
 }
 
@@ -540,7 +592,7 @@ int Engine::launch_relax(int mode) {
 // the device; the host peeks at them once per batch of launches (an empty launch
 // costs a few microseconds, a host round trip more).
 int Engine::run_phase(int mode, uint32_t *launches, float *kernel_ms) {
-    int batch = 4;
+    int batch = batch_fixed > 0 ? batch_fixed : 4;
     const long cap = 64L * (P.TX + P.TY) * T + 4096;   // generous bound on sweeps
     long total = 0;
     for (;;) {
@@ -567,10 +619,10 @@ int Engine::run_phase(int mode, uint32_t *launches, float *kernel_ms) {
                 HIPCHK(hipEventElapsedTime(&ms, ev[2 * k], ev[2 * k + 1]));
                 *kernel_ms += ms;
             }
-        const int active = h_ctr->cnt[buf];
+        const int active = h_ctr->ncand[buf];
         if (active == 0) return UFM_OK;
         if (total > cap) return UFM_ERR_NOT_CONVERGED;
-        batch = active > 256 ? 16 : (active > 32 ? 8 : 4);
+        batch = batch_fixed > 0 ? batch_fixed : (active > 256 ? 16 : (active > 32 ? 8 : 4));
     }
 }
 
@@ -592,8 +644,8 @@ int Engine::step(ufm_stats *out) {
     ufm_stats st{};
     const auto t0 = std::chrono::steady_clock::now();
 
-    HIPCHK(hipMemsetAsync(P.ctr, 0, offsetof(DevCounters, scount), stream));                 // cnt[3], tcount
-    HIPCHK(hipMemsetAsync(&P.ctr->not_converged, 0, sizeof(DevCounters) - offsetof(DevCounters, not_converged), stream));
+    HIPCHK(hipMemsetAsync(P.ctr, 0, offsetof(DevCounters, scount), stream));                 // ncand, nready, tcount
+    HIPCHK(hipMemsetAsync(&P.ctr->pad0, 0, sizeof(DevCounters) - offsetof(DevCounters, pad0), stream));
     buf = 0;
 
     // classify maps: (re)initialise, propagate pending patches, or idle  (ReplannerBase.h:48-59)
@@ -711,7 +763,7 @@ int engine_create(Engine **out, int n_maps, int algo, int opt_lvl, int use_heuri
     e->grid_relax = prop.multiProcessorCount * 2;
     HIPCHK(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
     HIPCHK(hipHostMalloc(&e->h_ctr, sizeof(DevCounters)));
-    HIPCHK(hipHostMalloc(&e->h_scratch, sizeof(int) * 6 * n_maps));
+    HIPCHK(hipHostMalloc(&e->h_scratch, sizeof(int) * (6 * n_maps + 4)));
     *out = e;
     return UFM_OK;
 }
@@ -743,7 +795,15 @@ int engine_set_map(Engine *e, int m, const uint8_t *src, bool on_device, int wid
     }
     HIPCHK(hipMemcpyAsync(e->P.cost + (size_t)m * e->P.cstride, src, (size_t)width * length,
                           on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, e->stream));
-    HIPCHK(hipStreamSynchronize(e->stream));
+    {   // mean traversable cost -> default ordering band
+        unsigned long long *d_acc = reinterpret_cast<unsigned long long *>(e->d_scratch);
+        HIPCHK(hipMemsetAsync(d_acc, 0, 2 * sizeof(unsigned long long), e->stream));
+        k_cost_stats<<<512, 256, 0, e->stream>>>(e->P.cost + (size_t)m * e->P.cstride, (size_t)width * length, e->thr_uchar, d_acc);
+        unsigned long long *h_acc = reinterpret_cast<unsigned long long *>(e->h_scratch);
+        HIPCHK(hipMemcpyAsync(h_acc, d_acc, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, e->stream));
+        HIPCHK(hipStreamSynchronize(e->stream));
+        if (h_acc[1] > 0) e->mean_cost = (float)((double)h_acc[0] / (double)h_acc[1]);
+    }
     e->maps[m].have_map = true;   // initialize_graph = false, ReplannerBase.h:87
     // goal element validity depends on the map size
     MapState &ms = e->maps[m];
@@ -857,6 +917,17 @@ int ufm_read_map(ufm_t *p, uint8_t *host_map) {
     HIPCHK(hipSetDevice(p->e->device));
     HIPCHK(hipMemcpyAsync(host_map, p->e->P.cost, p->e->P.cstride, hipMemcpyDeviceToHost, p->e->stream));
     HIPCHK(hipStreamSynchronize(p->e->stream));
+    return UFM_OK;
+}
+int ufm_set_param(ufm_t *p, const char *name, double value) {
+    if (!p || !name) return UFM_ERR_INVALID;
+    Engine *e = p->e;
+    if (!std::strcmp(name, "delta")) e->delta_abs = (float)value;
+    else if (!std::strcmp(name, "delta_scale")) { e->delta_scale = (float)value; e->delta_abs = -1.0f; }
+    else if (!std::strcmp(name, "max_iters")) e->max_iters = value < 1 ? 1 : (int)value;
+    else if (!std::strcmp(name, "batch")) e->batch_fixed = (int)value;
+    else if (!std::strcmp(name, "grid")) e->grid_relax = value < 1 ? 1 : (int)value;
+    else return UFM_ERR_INVALID;
     return UFM_OK;
 }
 int ufm_set_profiling(ufm_t *p, int enable) { if (!p) return UFM_ERR_INVALID; p->e->profiling = enable != 0; return UFM_OK; }
