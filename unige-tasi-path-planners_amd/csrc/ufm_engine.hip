@@ -107,29 +107,59 @@ __device__ __forceinline__ float sqrt_rn(float x) {
     s = (rp > 0.0f) ? sp : s;
     return s;
 }
-// ShiftedGridPlanner_impl.h:422-436 (+ InterpolatedTraversal.cpp:125-127,324-326,403-405)
-__device__ __forceinline__ float tri_sg(float g1, float g2, float c) {
-    const float f = g1 - g2;
-    const float tII = g1 + sqrt_rn(c * c - f * f);
-    const float tA = g2 + c * SQRT2F;
-    float r = (f * SQRT2F <= c) ? tII : tA;
-    r = (f <= 0.0f) ? (g1 + c) : r;
-    return (c == INFINITY) ? INFINITY : r;   // both g inf -> f NaN -> tA = inf
+// The traversal-cost case analyses below are evaluated branch-free: every quantity that
+// depends only on the cell costs is folded, once per tile visit, into per-lane constants chosen
+// so that IEEE comparisons/selects reproduce the reference's if/else chain exactly, including
+// the +inf (obstacle / unreached) cases.  `|` and `&` on bools are deliberate (no short-circuit
+// control flow in the sweep loop).
+
+// ShiftedGridPlanner_impl.h:422-436 (+ InterpolatedTraversal.cpp:125-127,324-326,403-405):
+//   g1,g2 both inf -> inf ; c inf -> inf ; f = g1-g2
+//   f <= 0 -> g1 + c ; f*SQRT2 <= c -> g1 + sqrt(c^2-f^2) ; else g2 + c*SQRT2
+struct CellSG {          // per cell c
+    float cadd;          // c (inf for an obstacle)
+    float ccmp;          // c, or -1 for an obstacle so that "f*SQRT2 <= c" fails and Type A (= inf) is taken
+    float c2, cs2;       // c*c, c*SQRT2
+    __device__ __forceinline__ void set(float c) {
+        cadd = c; ccmp = (c == INFINITY) ? -1.0f : c; c2 = c * c; cs2 = c * SQRT2F;
+    }
+};
+__device__ __forceinline__ float tri_sg(float g1, float g2, const CellSG &K) {
+    const float f = g1 - g2;                       // NaN when both inf -> every test false -> tA = inf
+    const float tII = g1 + sqrt_rn(K.c2 - f * f);
+    const float tA = g2 + K.cs2;
+    float r = (f * SQRT2F <= K.ccmp) ? tII : tA;
+    r = (f <= 0.0f) ? (g1 + K.cadd) : r;
+    return r;
 }
-// FieldDPlanner_impl.h:292-319 (+ InterpolatedTraversal.cpp:8-10,125-127,236-238,324-326,403-405)
-// cb = CATH(c,b) is constant during a tile visit and passed in.
-__device__ __forceinline__ float tri_fd(float g1, float g2, float b, float c, float cb) {
+
+// FieldDPlanner_impl.h:292-319 (+ InterpolatedTraversal.cpp:8-10,125-127,236-238,324-326,403-405):
+//   c > b : f<=0 or f^2 <= CATH(c,b) -> g1+b (III) ; f<=b and c > f*SQRT2 -> g1+CATH(c,f) (II) ;
+//           f>b and c > b*SQRT2 -> g2+b+CATH(c,b) (I) ; else g2+c*SQRT2 (A)
+//   c <= b: f<=0 -> g1+c (B) ; f*SQRT2 < c -> g1+CATH(c,f) (II) ; else (A)
+// Unified: with bp = (c>b ? b : c), cbp = (c>b ? CATH(c,b) : -1), bI = (c > b*SQRT2 ? b : inf)
+//   r = A ; if (f > bI) r = (g2+bp)+cbp ; if (f <= bp & c > f*SQRT2) r = II ; if (f<=0 | f^2 <= cbp) r = g1+bp
+// (for c <= b the test f <= bp=c is implied by f*SQRT2 < c; c = inf is folded as bp = inf.)
+struct CellFD { float c, c2, cs2; };
+struct TriFD {
+    float bp, cbp, bI;
+    __device__ __forceinline__ void set(float c, float b) {
+        const bool cgb = c > b;
+        bp = cgb ? b : c;
+        cbp = cgb ? sqrt_rn(c * c - b * b) : -1.0f;          // CATH(c,b), Macros.h:12
+        bI = (c > b * SQRT2F) ? b : INFINITY;
+        if (c == INFINITY) { bp = INFINITY; cbp = -1.0f; }
+    }
+};
+__device__ __forceinline__ float tri_fd(float g1, float g2, const CellFD &K, const TriFD &Q) {
     const float f = g1 - g2;
-    const float tII = g1 + sqrt_rn(c * c - f * f);
-    const float tA = g2 + c * SQRT2F;
-    const bool cIII = (f <= 0.0f) || (f * f <= cb);
-    const bool cII = (f <= b) && (c > f * SQRT2F);
-    const bool cI = (f > b) && (c > b * SQRT2F);
-    const float r1 = cIII ? (g1 + b) : (cII ? tII : (cI ? ((g2 + b) + cb) : tA));
-    const float r2 = (f <= 0.0f) ? (g1 + c) : ((f * SQRT2F < c) ? tII : tA);
-    const float r = (c > b) ? r1 : r2;
-    const bool dead = (c == INFINITY) || ((g1 == INFINITY) && (g2 == INFINITY));
-    return dead ? INFINITY : r;
+    const float ff = f * f;
+    const float tII = g1 + sqrt_rn(K.c2 - ff);
+    float r = g2 + K.cs2;                                                  // A
+    r = (f > Q.bI) ? ((g2 + Q.bp) + Q.cbp) : r;                            // I
+    r = ((f <= Q.bp) & (K.c > f * SQRT2F)) ? tII : r;                      // II
+    r = ((f <= 0.0f) | (ff <= Q.cbp)) ? (g1 + Q.bp) : r;                   // III / B
+    return r;
 }
 // DynamicFastMarching_impl.h:322-342
 __device__ __forceinline__ float q_dfm(float a, float b, float th) {
@@ -139,43 +169,65 @@ __device__ __forceinline__ float q_dfm(float a, float b, float th) {
     return (th > d) ? s : (ga + th);        // both inf -> d NaN -> ga + th = inf
 }
 
-struct NodeCosts {   // the four cells around a node (Node.cpp:44-50) and FD's CATH(c,b) terms
-    float c00, c01, c10, c11;
-    float k0, k1, k2, k3, k4, k5, k6, k7;
+// per-lane constants of one element for a tile visit
+template <int ALGO> struct ElemConsts;
+template <> struct ElemConsts<UFM_ALGO_DFM> {
+    float tau, tau_d;     // cost(c), cost(c)*SQRT2
+    __device__ __forceinline__ void load(const float *Cs, int lx, int ly) {
+        tau = Cs[lx * CP + ly]; tau_d = tau * SQRT2F;
+    }
+};
+template <> struct ElemConsts<UFM_ALGO_SG> {
+    CellSG k00, k01, k10, k11;   // the four cells around a node (Node.cpp:44-50)
+    __device__ __forceinline__ void load(const float *Cs, int lx, int ly) {
+        k00.set(Cs[lx * CP + ly]); k01.set(Cs[lx * CP + ly + 1]);
+        k10.set(Cs[(lx + 1) * CP + ly]); k11.set(Cs[(lx + 1) * CP + ly + 1]);
+    }
+};
+template <> struct ElemConsts<UFM_ALGO_FD> {
+    CellFD k00, k01, k10, k11;
+    TriFD q0, q1, q2, q3, q4, q5, q6, q7;   // per triangle: (c, b = cell across the edge s-p1), FD impl:322-337
+    __device__ __forceinline__ void load(const float *Cs, int lx, int ly) {
+        const float c00 = Cs[lx * CP + ly], c01 = Cs[lx * CP + ly + 1];
+        const float c10 = Cs[(lx + 1) * CP + ly], c11 = Cs[(lx + 1) * CP + ly + 1];
+        k00 = {c00, c00 * c00, c00 * SQRT2F}; k01 = {c01, c01 * c01, c01 * SQRT2F};
+        k10 = {c10, c10 * c10, c10 * SQRT2F}; k11 = {c11, c11 * c11, c11 * SQRT2F};
+        q0.set(c00, c01); q1.set(c00, c10); q2.set(c01, c00); q3.set(c01, c11);
+        q4.set(c10, c11); q5.set(c10, c00); q6.set(c11, c10); q7.set(c11, c01);
+    }
 };
 
 template <int ALGO>
-__device__ __forceinline__ float eval_elem(const float *Gs, int lx, int ly, const NodeCosts &C) {
+__device__ __forceinline__ float eval_elem(const float *Gs, int lx, int ly, const ElemConsts<ALGO> &C) {
     const float *ctr = Gs + (lx + 1) * GP + (ly + 1);
     const float gN = ctr[-GP], gS = ctr[GP], gW = ctr[-1], gE = ctr[1];
     const float gNW = ctr[-GP - 1], gNE = ctr[-GP + 1], gSW = ctr[GP - 1], gSE = ctr[GP + 1];
-    if (ALGO == UFM_ALGO_DFM) {
+    if constexpr (ALGO == UFM_ALGO_DFM) {
         // DynamicFastMarching_impl.h:157-210 (best_cell :344-351 reduces to a min on values)
-        const float tau = C.c00;
-        const float ortho = q_dfm(fminf(gN, gS), fminf(gW, gE), tau);
-        const float diag = q_dfm(fminf(gNW, gSE), fminf(gSW, gNE), tau * SQRT2F);
+        const float ortho = q_dfm(fminf(gN, gS), fminf(gW, gE), C.tau);
+        const float diag = q_dfm(fminf(gNW, gSE), fminf(gSW, gNE), C.tau_d);
         return (diag < ortho) ? diag : ortho;
-    } else if (ALGO == UFM_ALGO_SG) {
+    } else if constexpr (ALGO == UFM_ALGO_SG) {
         // ShiftedGridPlanner_impl.h:258-264 over the 8 triangles of Graph.cpp:202-230
-        float r = tri_sg(gN, gNW, C.c00);
-        r = fminf(r, tri_sg(gW, gNW, C.c00));
-        r = fminf(r, tri_sg(gN, gNE, C.c01));
-        r = fminf(r, tri_sg(gE, gNE, C.c01));
-        r = fminf(r, tri_sg(gS, gSW, C.c10));
-        r = fminf(r, tri_sg(gW, gSW, C.c10));
-        r = fminf(r, tri_sg(gS, gSE, C.c11));
-        r = fminf(r, tri_sg(gE, gSE, C.c11));
+        float r = tri_sg(gN, gNW, C.k00);
+        r = fminf(r, tri_sg(gW, gNW, C.k00));
+        r = fminf(r, tri_sg(gN, gNE, C.k01));
+        r = fminf(r, tri_sg(gE, gNE, C.k01));
+        r = fminf(r, tri_sg(gS, gSW, C.k10));
+        r = fminf(r, tri_sg(gW, gSW, C.k10));
+        r = fminf(r, tri_sg(gS, gSE, C.k11));
+        r = fminf(r, tri_sg(gE, gSE, C.k11));
         return r;
     } else {
-        // FieldDPlanner_impl.h:188-194; b = cell across the edge s-p1 (:322-337)
-        float r = tri_fd(gN, gNW, C.c01, C.c00, C.k0);
-        r = fminf(r, tri_fd(gW, gNW, C.c10, C.c00, C.k1));
-        r = fminf(r, tri_fd(gN, gNE, C.c00, C.c01, C.k2));
-        r = fminf(r, tri_fd(gE, gNE, C.c11, C.c01, C.k3));
-        r = fminf(r, tri_fd(gS, gSW, C.c11, C.c10, C.k4));
-        r = fminf(r, tri_fd(gW, gSW, C.c00, C.c10, C.k5));
-        r = fminf(r, tri_fd(gS, gSE, C.c10, C.c11, C.k6));
-        r = fminf(r, tri_fd(gE, gSE, C.c01, C.c11, C.k7));
+        // FieldDPlanner_impl.h:188-194
+        float r = tri_fd(gN, gNW, C.k00, C.q0);
+        r = fminf(r, tri_fd(gW, gNW, C.k00, C.q1));
+        r = fminf(r, tri_fd(gN, gNE, C.k01, C.q2));
+        r = fminf(r, tri_fd(gE, gNE, C.k01, C.q3));
+        r = fminf(r, tri_fd(gS, gSW, C.k10, C.q4));
+        r = fminf(r, tri_fd(gW, gSW, C.k10, C.q5));
+        r = fminf(r, tri_fd(gS, gSE, C.k11, C.q6));
+        r = fminf(r, tri_fd(gE, gSE, C.k11, C.q7));
         return r;
     }
 }
@@ -192,8 +244,9 @@ template <int ALGO, int MODE>
 __global__ __launch_bounds__(NTHR) void k_relax(DevParams P, int nb, int max_iters) {
     __shared__ float Gs[(T + 2) * GP];
     __shared__ float Cs[(T + 1) * CP];
-    __shared__ int s_dirty[2][16];
-    __shared__ int s_misc[4];   // 0: first touch, 2: wave evaluations
+    __shared__ int s_wake[16];  // per 8x8 patch: inputs changed since its last sweep
+    __shared__ int s_pending;   // set wake flags + sweeps in flight
+    __shared__ int s_misc[4];   // 0: first touch, 2: wave sweeps (sum), 3: wave sweeps (max)
     __shared__ int s_bmin[9];   // per direction: smallest changed value on that border (float bits)
 
     const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
@@ -214,9 +267,9 @@ __global__ __launch_bounds__(NTHR) void k_relax(DevParams P, int nb, int max_ite
         if (tid == 0) {
             const int first = atomicExch(&P.touched[gt], 1) == 0;
             if (first) P.tlist[atomicAdd(&P.ctr->tcount, 1)] = gt;
-            s_misc[0] = first; s_misc[2] = 0;
+            s_misc[0] = first; s_misc[2] = 0; s_misc[3] = 0; s_pending = 16;
         }
-        if (tid < 16) { s_dirty[0][tid] = 1; s_dirty[1][tid] = 0; }
+        if (tid < 16) s_wake[tid] = 1;
         if (tid >= 32 && tid < 41) s_bmin[tid - 32] = INFBITS;
 
         // stage G tile + halo (rows padded by one, columns by GPAD: no bounds checks)
@@ -241,66 +294,73 @@ __global__ __launch_bounds__(NTHR) void k_relax(DevParams P, int nb, int max_ite
         if (s_misc[0]) P.Gprev[(size_t)m * P.gstride + gidx] = gl0;
 
         float g = Gs[(lx + 1) * GP + ly + 1];
-        NodeCosts C;
-        C.c00 = Cs[lx * CP + ly];
-        if (ALGO != UFM_ALGO_DFM) {
-            C.c01 = Cs[lx * CP + ly + 1];
-            C.c10 = Cs[(lx + 1) * CP + ly];
-            C.c11 = Cs[(lx + 1) * CP + ly + 1];
-        }
-        if (ALGO == UFM_ALGO_FD) {   // CATH(c,b), Macros.h:12, per (c,b) pair of eval_elem
-            C.k0 = sqrt_rn(C.c00 * C.c00 - C.c01 * C.c01);
-            C.k1 = sqrt_rn(C.c00 * C.c00 - C.c10 * C.c10);
-            C.k2 = sqrt_rn(C.c01 * C.c01 - C.c00 * C.c00);
-            C.k3 = sqrt_rn(C.c01 * C.c01 - C.c11 * C.c11);
-            C.k4 = sqrt_rn(C.c10 * C.c10 - C.c11 * C.c11);
-            C.k5 = sqrt_rn(C.c10 * C.c10 - C.c00 * C.c00);
-            C.k6 = sqrt_rn(C.c11 * C.c11 - C.c10 * C.c10);
-            C.k7 = sqrt_rn(C.c11 * C.c11 - C.c01 * C.c01);
-        }
+        ElemConsts<ALGO> C;
+        C.load(Cs, lx, ly);
         const bool is_goal = (x0 + lx == P.goal[2 * m]) && (y0 + ly == P.goal[2 * m + 1]);
 
-        int cur = 0, it = 0, wave_evals = 0;
-        bool conv = false;
-        // Increases in the lowering phase are ulp-level corrections of values that were
-        // computed from transient neighbours.  Two neighbours that feed each other can
-        // flip-flop forever if they rise in the same sweep, so an element may only rise
-        // in sweeps of its own colour (4-colouring: no two 8-neighbours share one).
+        // Asynchronous in-LDS relaxation.  Each wave owns one 8x8 patch and sweeps it whenever its
+        // wake flag is set; a wave that changed values wakes the patches that read them.  No
+        // workgroup barrier per sweep: the critical path of a tile visit is the chain of dependent
+        // sweeps of the patches the front passes through, not 16 waves in lockstep.
+        // s_pending counts set flags + waves inside a sweep; 0 means the tile is at its fixed point.
+        // Increases in the lowering phase are ulp-level corrections of values computed from transient
+        // neighbours.  Two neighbours that feed each other can flip-flop forever if they rise in the
+        // same sweep, so an element may only rise in sweeps of its own colour (4-colouring: no two
+        // 8-neighbours share one).
         const int colour = (lx & 1) | ((ly & 1) << 1);
-        for (; it < max_iters; ++it) {
-            int want = 0;
-            if (s_dirty[cur][w]) {                       // wave-uniform
-                if (lane == 0) s_dirty[cur][w] = 0;
-                float nv = eval_elem<ALGO>(Gs, lx, ly, C);
-                if (is_goal) nv = 0.0f;                  // RHS(goal) = 0, *_impl.h init()
-                int doit;
-                if (MODE == MODE_LOWER) {
-                    want = (nv != g);                    // replace semantics: G <- F(G)
-                    doit = want && ((nv < g) || (colour == (it & 3)));
-                } else {
-                    want = (g < INFINITY) && (nv > g);   // value lost its support
-                    doit = want;
-                    nv = INFINITY;
-                }
-                if (doit) { g = nv; Gs[(lx + 1) * GP + ly + 1] = nv; }
-                const unsigned long long mask = __ballot(doit);
-                const unsigned long long deferred = __ballot(want && !doit);
-                if ((mask | deferred) && lane < 9) {     // wake the patches whose inputs changed
-                    const int dr = lane / 3 - 1, dc = lane % 3 - 1;
-                    unsigned long long sel = ~0ull;
-                    if (dr < 0) sel &= 0x00000000000000FFull; else if (dr > 0) sel &= 0xFF00000000000000ull;
-                    if (dc < 0) sel &= 0x0101010101010101ull; else if (dc > 0) sel &= 0x8080808080808080ull;
-                    const int pr = (w >> 2) + dr, pc = (w & 3) + dc;
-                    const bool self = (dr == 0) && (dc == 0);
-                    if (((mask & sel) || (self && deferred)) && pr >= 0 && pr < 4 && pc >= 0 && pc < 4)
-                        s_dirty[cur ^ 1][pr * 4 + pc] = 1;
-                }
-                ++wave_evals;
-            }
-            cur ^= 1;
-            if (!__syncthreads_or(want)) { conv = true; ++it; break; }
+        // lanes 0..8 each watch one of the 3x3 patches around this one: which lanes of this patch
+        // border it (wake_sel) and its wake flag (wake_tgt); lane 4 is the patch itself.
+        unsigned long long wake_sel = 0ull;
+        int wake_tgt = 0;
+        bool wake_self = false;
+        if (lane < 9) {
+            const int dr = lane / 3 - 1, dc = lane % 3 - 1;
+            unsigned long long sel = ~0ull;
+            if (dr < 0) sel &= 0x00000000000000FFull; else if (dr > 0) sel &= 0xFF00000000000000ull;
+            if (dc < 0) sel &= 0x0101010101010101ull; else if (dc > 0) sel &= 0x8080808080808080ull;
+            const int pr = (w >> 2) + dr, pc = (w & 3) + dc;
+            if (pr >= 0 && pr < 4 && pc >= 0 && pc < 4) { wake_sel = sel; wake_tgt = pr * 4 + pc; wake_self = (lane == 4); }
         }
-        if (lane == 0 && wave_evals) atomicAdd(&s_misc[2], wave_evals);
+        int sweeps = 0;
+        for (;;) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            const int pend = __hip_atomic_load(&s_pending, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (pend <= 0) break;                        // 0: converged, <0: sweep cap hit somewhere
+            int mine = 0;
+            if (lane == 0) mine = atomicExch(&s_wake[w], 0);
+            mine = __builtin_amdgcn_readfirstlane(mine);
+            if (!mine) { __builtin_amdgcn_s_sleep(2); continue; }
+            if (sweeps >= max_iters) {                   // give up this visit; the tile is re-queued
+                if (lane == 0) atomicExch(&s_pending, -(1 << 20));
+                break;
+            }
+            float nv = eval_elem<ALGO>(Gs, lx, ly, C);
+            if (is_goal) nv = 0.0f;                      // RHS(goal) = 0, *_impl.h init()
+            int want, doit;
+            if (MODE == MODE_LOWER) {
+                want = (nv != g);                        // replace semantics: G <- F(G)
+                doit = want && ((nv < g) || (colour == (sweeps & 3)));
+            } else {
+                want = (g < INFINITY) && (nv > g);       // value lost its support
+                doit = want;
+                nv = INFINITY;
+            }
+            if (doit) { g = nv; Gs[(lx + 1) * GP + ly + 1] = nv; }
+            const unsigned long long mask = __ballot(doit);
+            const unsigned long long deferred = __ballot(want && !doit);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            if (mask | deferred) {                       // wake the patches whose inputs changed
+                if (((mask & wake_sel) | (wake_self ? deferred : 0ull)) != 0ull)
+                    if (atomicExch(&s_wake[wake_tgt], 1) == 0) atomicAdd(&s_pending, 1);
+            }
+            ++sweeps;
+            if (lane == 0) atomicSub(&s_pending, 1);     // this sweep's token
+        }
+        __syncthreads();
+        const bool conv = __hip_atomic_load(&s_pending, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == 0;
+        if (lane == 0 && sweeps) atomicAdd(&s_misc[2], sweeps);
+        if (lane == 0) atomicMax(&s_misc[3], sweeps);
+        __syncthreads();
 
         // write back what changed; note which neighbours saw their halo change
         const float gf = Gs[(io_r + 1) * GP + io_c + 1];
@@ -321,7 +381,7 @@ __global__ __launch_bounds__(NTHR) void k_relax(DevParams P, int nb, int max_ite
             if (tid == 4) {
                 if (!conv) activate(P, nb, gt, min(s_bmin[4], INFBITS - 1));   // sweep cap hit: come back
                 atomicAdd(&P.ctr->tile_visits, 1ull);
-                atomicAdd(&P.ctr->tile_iters, (unsigned long long)it);
+                atomicAdd(&P.ctr->tile_iters, (unsigned long long)s_misc[3]);
                 atomicAdd(&P.ctr->elem_evals, 64ull * (unsigned long long)s_misc[2]);
             } else if (s_bmin[tid] != INFBITS) {
                 const int ntx = tx + dr, nty = ty + dc;
