@@ -52,6 +52,7 @@ typedef struct ufm_stats {
     uint32_t launches;         /* relax kernel launches in this step */
     uint32_t raise_launches;   /* of which in the invalidation phase */
     float kernel_ms;           /* summed relax-kernel time (HIP events) if profiling is on, else 0 */
+    uint64_t crit_sweeps;      /* profiling only: sum over launches of the slowest tile's sweep count */
 } ufm_stats;
 
 /* ---- lifetime: `PlannerT<OPT_LVL> planner{}` (e.g. Tests/Planners/FDSTAR/main.cpp:77) ---- */

@@ -12,6 +12,7 @@ ap.add_argument("--algo", default="FD")
 ap.add_argument("--scales", default="0.25,0.5,1,2,4,1e9")
 ap.add_argument("--max-iters", default="128")
 ap.add_argument("--reps", type=int, default=2)
+ap.add_argument("--profile", type=int, default=0)
 a = ap.parse_args()
 algo = {"FD": 0, "SG": 1, "DFM": 2}[a.algo]
 size, seed = a.size, 7
@@ -20,6 +21,7 @@ start, goal = ufm_amd.synth.start_goal(size, size)
 script = list(ufm_amd.synth.replan_script(seed, size, size, n_patches=a.patches))
 p = ufm_amd.Planner(algo, 1 if algo != 1 else 2)
 p.set_occupancy_threshold(1)
+p.set_profiling(a.profile)
 ref = None
 for mi in [int(v) for v in a.max_iters.split(",")]:
   for sc in [float(v) for v in a.scales.split(",")]:
@@ -31,7 +33,7 @@ for mi in [int(v) for v in a.max_iters.split(",")]:
         assert p.step() == 0
         t1 = time.perf_counter()
         s0 = p.stats.as_dict()
-        acc = dict(expanded=0, tile_visits=0, launches=0, raise_launches=0, elem_evals=0)
+        acc = dict(expanded=0, tile_visits=0, launches=0, raise_launches=0, elem_evals=0, tile_iters=0, kernel_ms=0.0, crit_sweeps=0)
         for k, s, top, left, patch in script:
             p.patch_map(patch, top, left); p.set_start(*s)
             assert p.step() == 0
@@ -43,3 +45,6 @@ for mi in [int(v) for v in a.max_iters.split(",")]:
     print("scale %-6g maxit %3d | plan %7.2f ms visits %7d launches %5d evals/elem %6.1f | %d replans %7.2f ms visits %7d launches %5d (raise %5d) cells %8d | same=%s" % (
         sc, mi, (t1 - t0) * 1e3, s0["tile_visits"], s0["launches"], s0["elem_evals"] / max(1, s0["expanded"]),
         len(script), (t2 - t1) * 1e3, acc["tile_visits"], acc["launches"], acc["raise_launches"], acc["expanded"], same), flush=True)
+    print("      plan: sweeps/visit(max wave) %.1f  evals/visit %.0f kernel_ms %.2f crit_sweeps/launch %.1f | replans: sweeps/visit %.1f evals/visit %.0f kernel_ms %.2f crit_sweeps/launch %.1f" % (
+        s0["tile_iters"] / max(1, s0["tile_visits"]), s0["elem_evals"] / max(1, s0["tile_visits"]), s0["kernel_ms"], s0["crit_sweeps"] / max(1, s0["launches"]),
+        acc["tile_iters"] / max(1, acc["tile_visits"]), acc["elem_evals"] / max(1, acc["tile_visits"]), acc["kernel_ms"], acc["crit_sweeps"] / max(1, acc["launches"])), flush=True)

@@ -35,6 +35,7 @@ class Stats(C.Structure):
         ("tile_visits", C.c_uint64), ("tile_iters", C.c_uint64), ("elem_evals", C.c_uint64),
         ("launches", C.c_uint32), ("raise_launches", C.c_uint32),
         ("kernel_ms", C.c_float),
+        ("crit_sweeps", C.c_uint64),
     ]
 
     def as_dict(self):
@@ -42,7 +43,8 @@ class Stats(C.Structure):
 
 
 def library_path():
-    return os.path.join(_HERE, "libufm.so")
+    # UFM_LIB: alternative build of the same library (kernel tuning experiments)
+    return os.environ.get("UFM_LIB") or os.path.join(_HERE, "libufm.so")
 
 
 def build_library():

@@ -37,16 +37,19 @@ constexpr int T = 32;          // tile edge (elements)
 constexpr int GP = 40;         // LDS pitch of the G tile: rows 8 apart hit distinct banks
 constexpr int CP = 34;         // LDS pitch of the cost tile
 constexpr int NTHR = 1024;     // one element per lane, 16 waves, each owns an 8x8 patch
+#ifndef UFM_IDLE_SLEEP
+#define UFM_IDLE_SLEEP 4
+#endif
 constexpr int GPAD = 32;       // left padding (floats) so tile rows start 128-B aligned
 constexpr float SQRT2F = 1.41421356237309504880168872420969807856967187537694f;  // Macros.cpp:2
 
 enum { MODE_LOWER = 0, MODE_RAISE = 1 };
 
+constexpr int LMAX = 8192;
 constexpr int INFBITS = 0x7F800000;   // +inf as int: non-negative floats order like their bits
 
 struct DevCounters {
-    int ncand[2];               // candidate-list lengths (double buffer)
-    int nready;                 // tiles released by the last triage
+    int cnt[3];                 // candidate-list lengths (ring of three, see k_relax)
     int tcount;                 // touched-list length
     int scount;                 // pending-seed-list length (survives steps)
     int pad0;
@@ -61,10 +64,9 @@ struct DevParams {
     float *Gprev;               // snapshot of a tile at its first touch in a step
     uint8_t *cost;              // [nmaps][L][W]
     int *goal;                  // [nmaps][2]
-    int *cand;                  // [2][NT] queued tiles (global tile ids), double buffer
-    int *ready;                 // [NT] tiles released for the current relax launch
-    int *queued;                // [NT] tile is in a candidate list
-    int *prio;                  // [NT] float bits: smallest value that entered the tile since its last visit
+    int *cand;                  // [3][NT] queued tiles (global tile ids), ring of three lists
+    int *queued;                // [2][NT] tile is in the candidate list of that launch parity
+    int *prio;                  // [2][NT] float bits: smallest value that entered the tile since its last visit
     int *touched;               // [NT]
     int *tlist;                 // [NT]
     int *sflag;                 // [NT] pending seeds (from patches)
@@ -73,6 +75,7 @@ struct DevParams {
     unsigned int *mark;         // [nmaps][markwords] bitmap of seeded elements
     unsigned int *num_updated;  // [nmaps]
     int *consume;               // [nmaps]
+    int *lmax;                  // [LMAX] diagnostics: per launch, the largest per-wave sweep count of any tile
     DevCounters *ctr;
     int EX, EY;                 // elements per map (nodes or cells)
     int L, W;                   // cells per map
@@ -84,11 +87,12 @@ struct DevParams {
     size_t mstride;             // words per map in mark
 };
 
-__device__ __forceinline__ void activate(const DevParams &P, int nb, int gt, int pbits) {
-    atomicMin(&P.prio[gt], pbits);
-    if (atomicExch(&P.queued[gt], 1) == 0) {
-        const int k = atomicAdd(&P.ctr->ncand[nb], 1);
-        P.cand[nb * P.NT + k] = gt;
+// queue tile gt for the launch that reads list `lst` / priority parity `par`
+__device__ __forceinline__ void activate(const DevParams &P, int lst, int par, int gt, int pbits) {
+    atomicMin(&P.prio[par * P.NT + gt], pbits);
+    if (atomicExch(&P.queued[par * P.NT + gt], 1) == 0) {
+        const int k = atomicAdd(&P.ctr->cnt[lst], 1);
+        P.cand[lst * P.NT + k] = gt;
     }
 }
 
@@ -169,66 +173,67 @@ __device__ __forceinline__ float q_dfm(float a, float b, float th) {
     return (th > d) ? s : (ga + th);        // both inf -> d NaN -> ga + th = inf
 }
 
-// per-lane constants of one element for a tile visit
-template <int ALGO> struct ElemConsts;
-template <> struct ElemConsts<UFM_ALGO_DFM> {
-    float tau, tau_d;     // cost(c), cost(c)*SQRT2
-    __device__ __forceinline__ void load(const float *Cs, int lx, int ly) {
-        tau = Cs[lx * CP + ly]; tau_d = tau * SQRT2F;
+// ---- quad evaluation ---------------------------------------------------------------------
+// The eight triangles around a node split naturally by the cell they lie in.  Four adjacent
+// lanes (a DPP quad) own one node; lane q evaluates the two triangles of cell q (same c, same
+// diagonal neighbour) and a two-step quad_perm min gives RHS to all four lanes.  The dependent
+// instruction chain of one sweep -- what the critical path of a tile visit is made of -- is a
+// quarter of the one-lane-per-node form.  Cell q of node (x,y): (x-1+dx, y-1+dy), dx=q>>1, dy=q&1;
+// its triangles: (p1 = vertical neighbour, p2 = diagonal) and (p1 = horizontal neighbour, p2).
+template <int ALGO> struct QuadConsts;
+template <> struct QuadConsts<UFM_ALGO_DFM> {
+    float th;   // lane 0: cost (orthogonal stencil, h = 1); lane 1: cost*SQRT2 (diagonal stencil)
+    __device__ __forceinline__ void load(const float *Cs, int lx, int ly, int q) {
+        const float tau = Cs[lx * CP + ly];
+        th = (q & 1) ? tau * SQRT2F : tau;
     }
 };
-template <> struct ElemConsts<UFM_ALGO_SG> {
-    CellSG k00, k01, k10, k11;   // the four cells around a node (Node.cpp:44-50)
-    __device__ __forceinline__ void load(const float *Cs, int lx, int ly) {
-        k00.set(Cs[lx * CP + ly]); k01.set(Cs[lx * CP + ly + 1]);
-        k10.set(Cs[(lx + 1) * CP + ly]); k11.set(Cs[(lx + 1) * CP + ly + 1]);
+template <> struct QuadConsts<UFM_ALGO_SG> {
+    CellSG k;
+    __device__ __forceinline__ void load(const float *Cs, int lx, int ly, int q) {
+        k.set(Cs[(lx + (q >> 1)) * CP + ly + (q & 1)]);
     }
 };
-template <> struct ElemConsts<UFM_ALGO_FD> {
-    CellFD k00, k01, k10, k11;
-    TriFD q0, q1, q2, q3, q4, q5, q6, q7;   // per triangle: (c, b = cell across the edge s-p1), FD impl:322-337
-    __device__ __forceinline__ void load(const float *Cs, int lx, int ly) {
-        const float c00 = Cs[lx * CP + ly], c01 = Cs[lx * CP + ly + 1];
-        const float c10 = Cs[(lx + 1) * CP + ly], c11 = Cs[(lx + 1) * CP + ly + 1];
-        k00 = {c00, c00 * c00, c00 * SQRT2F}; k01 = {c01, c01 * c01, c01 * SQRT2F};
-        k10 = {c10, c10 * c10, c10 * SQRT2F}; k11 = {c11, c11 * c11, c11 * SQRT2F};
-        q0.set(c00, c01); q1.set(c00, c10); q2.set(c01, c00); q3.set(c01, c11);
-        q4.set(c10, c11); q5.set(c10, c00); q6.set(c11, c10); q7.set(c11, c01);
+template <> struct QuadConsts<UFM_ALGO_FD> {
+    CellFD k;
+    TriFD tv, th;   // b = the cell across the edge s-p1 (FieldDPlanner_impl.h:322-337)
+    __device__ __forceinline__ void load(const float *Cs, int lx, int ly, int q) {
+        const int dx = q >> 1, dy = q & 1;
+        const float c = Cs[(lx + dx) * CP + ly + dy];
+        const float bv = Cs[(lx + dx) * CP + ly + 1 - dy];   // across the vertical edge s-p1
+        const float bh = Cs[(lx + 1 - dx) * CP + ly + dy];   // across the horizontal edge s-p1
+        k = {c, c * c, c * SQRT2F};
+        tv.set(c, bv);
+        th.set(c, bh);
     }
 };
 
+__device__ __forceinline__ float quad_min(float v) {
+    int x = __float_as_int(v);
+    v = fminf(v, __int_as_float(__builtin_amdgcn_update_dpp(x, x, 0xB1, 0xF, 0xF, false)));   // quad_perm [1,0,3,2]
+    x = __float_as_int(v);
+    return fminf(v, __int_as_float(__builtin_amdgcn_update_dpp(x, x, 0x4E, 0xF, 0xF, false)));   // quad_perm [2,3,0,1]
+}
+
+// ctr points at the node inside the LDS tile; returns this lane's share of RHS(node)
 template <int ALGO>
-__device__ __forceinline__ float eval_elem(const float *Gs, int lx, int ly, const ElemConsts<ALGO> &C) {
-    const float *ctr = Gs + (lx + 1) * GP + (ly + 1);
-    const float gN = ctr[-GP], gS = ctr[GP], gW = ctr[-1], gE = ctr[1];
-    const float gNW = ctr[-GP - 1], gNE = ctr[-GP + 1], gSW = ctr[GP - 1], gSE = ctr[GP + 1];
+__device__ __forceinline__ float eval_quad(const float *ctr, int q, const QuadConsts<ALGO> &C) {
     if constexpr (ALGO == UFM_ALGO_DFM) {
-        // DynamicFastMarching_impl.h:157-210 (best_cell :344-351 reduces to a min on values)
-        const float ortho = q_dfm(fminf(gN, gS), fminf(gW, gE), C.tau);
-        const float diag = q_dfm(fminf(gNW, gSE), fminf(gSW, gNE), C.tau_d);
-        return (diag < ortho) ? diag : ortho;
-    } else if constexpr (ALGO == UFM_ALGO_SG) {
-        // ShiftedGridPlanner_impl.h:258-264 over the 8 triangles of Graph.cpp:202-230
-        float r = tri_sg(gN, gNW, C.k00);
-        r = fminf(r, tri_sg(gW, gNW, C.k00));
-        r = fminf(r, tri_sg(gN, gNE, C.k01));
-        r = fminf(r, tri_sg(gE, gNE, C.k01));
-        r = fminf(r, tri_sg(gS, gSW, C.k10));
-        r = fminf(r, tri_sg(gW, gSW, C.k10));
-        r = fminf(r, tri_sg(gS, gSE, C.k11));
-        r = fminf(r, tri_sg(gE, gSE, C.k11));
+        // DynamicFastMarching_impl.h:157-210: best_cell (:344-351) is a min on values, and
+        // "diag < ortho ? diag : ortho" is the quad min of the two stencil solves
+        float r = INFINITY;
+        if (q < 2) {
+            const int a = q ? -GP - 1 : -GP, b = q ? GP + 1 : GP, c = q ? GP - 1 : -1, d = q ? -GP + 1 : 1;
+            r = q_dfm(fminf(ctr[a], ctr[b]), fminf(ctr[c], ctr[d]), C.th);
+        }
         return r;
     } else {
-        // FieldDPlanner_impl.h:188-194
-        float r = tri_fd(gN, gNW, C.k00, C.q0);
-        r = fminf(r, tri_fd(gW, gNW, C.k00, C.q1));
-        r = fminf(r, tri_fd(gN, gNE, C.k01, C.q2));
-        r = fminf(r, tri_fd(gE, gNE, C.k01, C.q3));
-        r = fminf(r, tri_fd(gS, gSW, C.k10, C.q4));
-        r = fminf(r, tri_fd(gW, gSW, C.k10, C.q5));
-        r = fminf(r, tri_fd(gS, gSE, C.k11, C.q6));
-        r = fminf(r, tri_fd(gE, gSE, C.k11, C.q7));
-        return r;
+        const int sx = (q & 2) ? GP : -GP, sy = (q & 1) ? 1 : -1;
+        const float gD = ctr[sx + sy], gV = ctr[sx], gH = ctr[sy];
+        if constexpr (ALGO == UFM_ALGO_SG)   // ShiftedGridPlanner_impl.h:258-264
+            return fminf(tri_sg(gV, gD, C.k), tri_sg(gH, gD, C.k));
+        else                                 // FieldDPlanner_impl.h:188-194
+            return fminf(tri_fd(gV, gD, C.k, C.tv), tri_fd(gH, gD, C.k, C.th));
     }
 }
 
@@ -239,25 +244,68 @@ __device__ __forceinline__ float cell_cost(const DevParams &P, const uint8_t *cm
     return (c >= P.thr) ? INFINITY : (float)c;
 }
 
-// ---- the hot kernel: one workgroup relaxes one active tile at a time ----------
+// ---- the hot kernel ------------------------------------------------------------------------
+// Launch k reads candidate list k%3 (priorities of parity k&1), appends to list (k+1)%3
+// (parity (k+1)&1) and recycles the counter of list (k+2)%3.
+//  1. triage (fused, every workgroup redundantly): theta = smallest queued priority + delta.
+//     Tiles above theta are carried over untouched -- their inputs are still going to improve
+//     (tile-level fast-marching order); delta = +inf is plain FIM (used for invalidation).
+//  2. each released tile is staged in LDS (+1 halo), relaxed to its fixed point by 16 waves that
+//     sweep 4x4-node patches asynchronously (wake bits in LDS, no workgroup barrier per sweep),
+//     written back, and the neighbours whose halo changed are queued with the smallest changed
+//     value as priority.
 template <int ALGO, int MODE>
-__global__ __launch_bounds__(NTHR) void k_relax(DevParams P, int nb, int max_iters) {
+__global__ __launch_bounds__(NTHR) void k_relax(DevParams P, int k, float delta, int max_sweeps) {
     __shared__ float Gs[(T + 2) * GP];
     __shared__ float Cs[(T + 1) * CP];
-    __shared__ int s_wake[16];  // per 8x8 patch: inputs changed since its last sweep
-    __shared__ int s_pending;   // set wake flags + sweeps in flight
-    __shared__ int s_misc[4];   // 0: first touch, 2: wave sweeps (sum), 3: wave sweeps (max)
+    __shared__ int s_wake[16];  // per wave: bit j = patch j of the wave has new inputs
+    __shared__ int s_idle;      // waves currently without work
+    __shared__ int s_giveup;    // a wave hit the sweep cap: end the visit, re-queue the tile
+    __shared__ int s_misc[4];   // 0: first touch, 2: patch sweeps (sum), 3: patch sweeps (max per wave)
     __shared__ int s_bmin[9];   // per direction: smallest changed value on that border (float bits)
+    __shared__ int s_min;
 
     const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
-    const int lx = (w >> 2) * 8 + (lane >> 3), ly = (w & 3) * 8 + (lane & 7);   // compute mapping
-    const int io_r = tid >> 5, io_c = tid & 31;                                 // HBM mapping
-    const int n = P.ctr->nready;
+    const int q = lane & 3, nd = lane >> 2;                    // quad lane, node within the 4x4 patch
+    const int wr = w >> 2, wc = w & 3;                         // the wave's 8x8 region = 2x2 patches
+    const int io_r = tid >> 5, io_c = tid & 31;                // HBM mapping
+    const int r = k % 3, rn = (k + 1) % 3, rz = (k + 2) % 3, pc = k & 1, pn = pc ^ 1;
+    const int n = P.ctr->cnt[r];
+    if (blockIdx.x == 0 && tid == 0) P.ctr->cnt[rz] = 0;
+    if (n == 0) return;
     constexpr int CROWS = (ALGO == UFM_ALGO_DFM) ? T : T + 1;
     constexpr int COFF = (ALGO == UFM_ALGO_DFM) ? 0 : 1;
 
+    if (tid == 0) s_min = INFBITS;
+    __syncthreads();
+    {
+        int lmin = INFBITS;
+        for (int i = tid; i < n; i += NTHR) lmin = min(lmin, P.prio[pc * P.NT + P.cand[r * P.NT + i]]);
+        if (lmin != INFBITS) atomicMin(&s_min, lmin);
+    }
+    __syncthreads();
+    const float theta = __int_as_float(s_min) + delta;
+
+    // lanes 0..8 each watch one of the 3x3 patches around the one being swept: the lanes of the
+    // patch that border it (wake_sel); lane 4 is the patch itself
+    unsigned long long wake_sel = 0ull;
+    if (lane < 9) {
+        const int dr = lane / 3 - 1, dc = lane % 3 - 1;
+        wake_sel = ~0ull;
+        if (dr < 0) wake_sel &= 0x000000000000FFFFull; else if (dr > 0) wake_sel &= 0xFFFF000000000000ull;
+        if (dc < 0) wake_sel &= 0x000F000F000F000Full; else if (dc > 0) wake_sel &= 0xF000F000F000F000ull;
+    }
+    const int colour = ((nd >> 2) & 1) | ((nd & 1) << 1);
+
     for (int i = blockIdx.x; i < n; i += gridDim.x) {
-        const int gt = P.ready[i];
+        const int gt = P.cand[r * P.NT + i];
+        const int pbits = P.prio[pc * P.NT + gt];
+        __syncthreads();                                   // everyone holds pbits; LDS of the previous tile is free
+        if (tid == 0) { P.queued[pc * P.NT + gt] = 0; P.prio[pc * P.NT + gt] = INFBITS; }
+        if (__int_as_float(pbits) > theta) {               // not yet: carry over
+            if (tid == 0) activate(P, rn, pn, gt, pbits);
+            continue;
+        }
         const int m = gt / P.NTm, t = gt - m * P.NTm;
         const int tx = t / P.TY, ty = t - tx * P.TY;
         const int x0 = tx * T, y0 = ty * T;
@@ -267,9 +315,9 @@ __global__ __launch_bounds__(NTHR) void k_relax(DevParams P, int nb, int max_ite
         if (tid == 0) {
             const int first = atomicExch(&P.touched[gt], 1) == 0;
             if (first) P.tlist[atomicAdd(&P.ctr->tcount, 1)] = gt;
-            s_misc[0] = first; s_misc[2] = 0; s_misc[3] = 0; s_pending = 16;
+            s_misc[0] = first; s_misc[2] = 0; s_misc[3] = 0; s_idle = 0; s_giveup = 0;
         }
-        if (tid < 16) s_wake[tid] = 1;
+        if (tid < 16) s_wake[tid] = 0xF;
         if (tid >= 32 && tid < 41) s_bmin[tid - 32] = INFBITS;
 
         // stage G tile + halo (rows padded by one, columns by GPAD: no bounds checks)
@@ -293,73 +341,104 @@ __global__ __launch_bounds__(NTHR) void k_relax(DevParams P, int nb, int max_ite
         __syncthreads();
         if (s_misc[0]) P.Gprev[(size_t)m * P.gstride + gidx] = gl0;
 
-        float g = Gs[(lx + 1) * GP + ly + 1];
-        ElemConsts<ALGO> C;
-        C.load(Cs, lx, ly);
-        const bool is_goal = (x0 + lx == P.goal[2 * m]) && (y0 + ly == P.goal[2 * m + 1]);
+        // per-lane constants of the wave's four patches
+        QuadConsts<ALGO> C[4];
+        int off[4], wword[4], wbit[4];
+        bool goal[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int lx = wr * 8 + (j >> 1) * 4 + (nd >> 2), ly = wc * 8 + (j & 1) * 4 + (nd & 3);
+            C[j].load(Cs, lx, ly, q);
+            off[j] = (lx + 1) * GP + ly + 1;
+            goal[j] = (x0 + lx == P.goal[2 * m]) && (y0 + ly == P.goal[2 * m + 1]);
+            wword[j] = 0; wbit[j] = 0;
+            if (lane < 9) {
+                const int gr = wr * 2 + (j >> 1) + lane / 3 - 1, gc = wc * 2 + (j & 1) + lane % 3 - 1;   // 8x8 patch grid
+                if (gr >= 0 && gr < 8 && gc >= 0 && gc < 8) { wword[j] = (gr >> 1) * 4 + (gc >> 1); wbit[j] = 1 << ((gr & 1) * 2 + (gc & 1)); }
+            }
+        }
 
-        // Asynchronous in-LDS relaxation.  Each wave owns one 8x8 patch and sweeps it whenever its
-        // wake flag is set; a wave that changed values wakes the patches that read them.  No
-        // workgroup barrier per sweep: the critical path of a tile visit is the chain of dependent
-        // sweeps of the patches the front passes through, not 16 waves in lockstep.
-        // s_pending counts set flags + waves inside a sweep; 0 means the tile is at its fixed point.
-        // Increases in the lowering phase are ulp-level corrections of values computed from transient
-        // neighbours.  Two neighbours that feed each other can flip-flop forever if they rise in the
-        // same sweep, so an element may only rise in sweeps of its own colour (4-colouring: no two
-        // 8-neighbours share one).
-        const int colour = (lx & 1) | ((ly & 1) << 1);
-        // lanes 0..8 each watch one of the 3x3 patches around this one: which lanes of this patch
-        // border it (wake_sel) and its wake flag (wake_tgt); lane 4 is the patch itself.
-        unsigned long long wake_sel = 0ull;
-        int wake_tgt = 0;
-        bool wake_self = false;
-        if (lane < 9) {
-            const int dr = lane / 3 - 1, dc = lane % 3 - 1;
-            unsigned long long sel = ~0ull;
-            if (dr < 0) sel &= 0x00000000000000FFull; else if (dr > 0) sel &= 0xFF00000000000000ull;
-            if (dc < 0) sel &= 0x0101010101010101ull; else if (dc > 0) sel &= 0x8080808080808080ull;
-            const int pr = (w >> 2) + dr, pc = (w & 3) + dc;
-            if (pr >= 0 && pr < 4 && pc >= 0 && pc < 4) { wake_sel = sel; wake_tgt = pr * 4 + pc; wake_self = (lane == 4); }
-        }
-        int sweeps = 0;
+        // Asynchronous in-LDS relaxation.  A wave takes the wake bits of its four patches and
+        // sweeps each woken patch in a burst: as long as the patch keeps changing itself it is
+        // re-swept back to back with no synchronisation at all (LDS operations of one wave are
+        // ordered); neighbouring patches are woken by fire-and-forget ds_or.  A wave without work
+        // counts itself idle and polls; when all 16 are idle a two-step barrier vote (arrive, then
+        // look at the wake bits, which are stable once everybody has arrived) decides between
+        // "converged" and "resume".
+        // Increases in the lowering phase are ulp-level corrections of values computed from
+        // transient neighbours.  Two neighbours that feed each other can flip-flop forever if they
+        // rise in the same sweep, so an element may only rise in sweeps of its own colour
+        // (4-colouring: no two 8-neighbours share one).
+        int cnt[4] = {0, 0, 0, 0};
+        int tot = 0;
+        bool conv = false;
         for (;;) {
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-            const int pend = __hip_atomic_load(&s_pending, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            if (pend <= 0) break;                        // 0: converged, <0: sweep cap hit somewhere
-            int mine = 0;
-            if (lane == 0) mine = atomicExch(&s_wake[w], 0);
-            mine = __builtin_amdgcn_readfirstlane(mine);
-            if (!mine) { __builtin_amdgcn_s_sleep(2); continue; }
-            if (sweeps >= max_iters) {                   // give up this visit; the tile is re-queued
-                if (lane == 0) atomicExch(&s_pending, -(1 << 20));
-                break;
+            int bits = 0;
+            if (lane == 0) bits = atomicExch(&s_wake[w], 0);
+            bits = __builtin_amdgcn_readfirstlane(bits);
+            bool vote = __hip_atomic_load(&s_giveup, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != 0;
+            if (bits && !vote) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    if (!(bits & (1 << j))) continue;    // wave-uniform
+                    float *ctr = Gs + off[j];
+                    bool again = true;
+                    for (int b = 0; b < 16 && again; ++b) {
+                        asm volatile("" ::: "memory");   // re-read the LDS tile every sweep (other waves and lanes write it)
+                        float nv = quad_min(eval_quad<ALGO>(ctr, q, C[j]));
+                        const float g = ctr[0];
+                        if (goal[j]) nv = 0.0f;          // RHS(goal) = 0, *_impl.h init()
+                        int want, doit;
+                        if (MODE == MODE_LOWER) {
+                            want = (nv != g);            // replace semantics: G <- F(G)
+                            doit = want & ((nv < g) | (colour == (cnt[j] & 3)));
+                        } else {
+                            want = (g < INFINITY) & (nv > g);   // value lost its support
+                            doit = want;
+                            nv = INFINITY;
+                        }
+                        if (doit && q == 0) ctr[0] = nv;
+                        const unsigned long long mask = __ballot(doit);
+                        const unsigned long long deferred = __ballot(want && !doit);
+                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // value before wake bit
+                        if ((mask & wake_sel) != 0ull && wbit[j] && lane != 4)
+                            __hip_atomic_fetch_or(&s_wake[wword[j]], wbit[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        ++cnt[j];
+                        ++tot;
+                        again = (mask | deferred) != 0ull;
+                    }
+                    if (again && lane == 0)              // burst cap: leave the rest to the next take
+                        __hip_atomic_fetch_or(&s_wake[w], 1 << j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
+                if (tot >= 4 * max_sweeps && lane == 0)  // give up this visit; the tile is re-queued
+                    __hip_atomic_store(&s_giveup, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                continue;
             }
-            float nv = eval_elem<ALGO>(Gs, lx, ly, C);
-            if (is_goal) nv = 0.0f;                      // RHS(goal) = 0, *_impl.h init()
-            int want, doit;
-            if (MODE == MODE_LOWER) {
-                want = (nv != g);                        // replace semantics: G <- F(G)
-                doit = want && ((nv < g) || (colour == (sweeps & 3)));
-            } else {
-                want = (g < INFINITY) && (nv > g);       // value lost its support
-                doit = want;
-                nv = INFINITY;
+            if (!vote) {                                 // nothing to do: idle until woken or all idle
+                if (bits && lane == 0) __hip_atomic_fetch_or(&s_wake[w], bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                if (lane == 0) atomicAdd(&s_idle, 1);
+                for (;;) {
+                    __builtin_amdgcn_s_sleep(UFM_IDLE_SLEEP);
+                    if (__hip_atomic_load(&s_idle, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >= 16 ||
+                        __hip_atomic_load(&s_giveup, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != 0) { vote = true; break; }
+                    if (__hip_atomic_load(&s_wake[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != 0) {
+                        if (lane == 0) atomicSub(&s_idle, 1);
+                        break;
+                    }
+                }
+                if (!vote) continue;
+            } else if (bits && lane == 0) {
+                __hip_atomic_fetch_or(&s_wake[w], bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // put back what was taken
             }
-            if (doit) { g = nv; Gs[(lx + 1) * GP + ly + 1] = nv; }
-            const unsigned long long mask = __ballot(doit);
-            const unsigned long long deferred = __ballot(want && !doit);
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-            if (mask | deferred) {                       // wake the patches whose inputs changed
-                if (((mask & wake_sel) | (wake_self ? deferred : 0ull)) != 0ull)
-                    if (atomicExch(&s_wake[wake_tgt], 1) == 0) atomicAdd(&s_pending, 1);
-            }
-            ++sweeps;
-            if (lane == 0) atomicSub(&s_pending, 1);     // this sweep's token
+            // vote: everybody arrives first, then the wake bits are stable
+            __syncthreads();
+            const int work = __syncthreads_or(__hip_atomic_load(&s_wake[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != 0);
+            const int gave_up = __hip_atomic_load(&s_giveup, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (gave_up || !work) { conv = !gave_up; break; }
+            if (tid == 0) s_idle = 0;
+            __syncthreads();
         }
-        __syncthreads();
-        const bool conv = __hip_atomic_load(&s_pending, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == 0;
-        if (lane == 0 && sweeps) atomicAdd(&s_misc[2], sweeps);
-        if (lane == 0) atomicMax(&s_misc[3], sweeps);
+        if (lane == 0 && tot) { atomicAdd(&s_misc[2], tot); atomicMax(&s_misc[3], tot); }
         __syncthreads();
 
         // write back what changed; note which neighbours saw their halo change
@@ -379,16 +458,16 @@ __global__ __launch_bounds__(NTHR) void k_relax(DevParams P, int nb, int max_ite
         if (tid < 9) {
             const int dr = tid / 3 - 1, dc = tid % 3 - 1;
             if (tid == 4) {
-                if (!conv) activate(P, nb, gt, min(s_bmin[4], INFBITS - 1));   // sweep cap hit: come back
+                if (!conv) activate(P, rn, pn, gt, min(s_bmin[4], INFBITS - 1));   // sweep cap hit: come back
+                atomicMax(&P.lmax[k & (LMAX - 1)], s_misc[3]);
                 atomicAdd(&P.ctr->tile_visits, 1ull);
                 atomicAdd(&P.ctr->tile_iters, (unsigned long long)s_misc[3]);
-                atomicAdd(&P.ctr->elem_evals, 64ull * (unsigned long long)s_misc[2]);
+                atomicAdd(&P.ctr->elem_evals, 16ull * (unsigned long long)s_misc[2]);
             } else if (s_bmin[tid] != INFBITS) {
                 const int ntx = tx + dr, nty = ty + dc;
-                if (ntx >= 0 && ntx < P.TX && nty >= 0 && nty < P.TY) activate(P, nb, m * P.NTm + ntx * P.TY + nty, s_bmin[tid]);
+                if (ntx >= 0 && ntx < P.TX && nty >= 0 && nty < P.TY) activate(P, rn, pn, m * P.NTm + ntx * P.TY + nty, s_bmin[tid]);
             }
         }
-        __syncthreads();
     }
 }
 
@@ -432,53 +511,27 @@ __global__ void k_clear_marks(DevParams P, int m, int x, int y, int w, int h) {
     const size_t el = (size_t)ex * P.EY + ey;
     P.mark[(size_t)m * P.mstride + (el >> 5)] = 0u;
 }
-// pending seeds of consuming maps -> active list `buf`; others stay pending. One block.
-__global__ void k_seeds_to_active(DevParams P, int buf) {
+// pending seeds of consuming maps -> candidate list of launch k; others stay pending. One block.
+__global__ void k_seeds_to_active(DevParams P, int k) {
     __shared__ int s_keep;
     if (threadIdx.x == 0) s_keep = 0;
     __syncthreads();
     const int n = P.ctr->scount;
     for (int i = threadIdx.x; i < n; i += blockDim.x) {
         const int gt = P.slist[i];
-        if (P.consume[gt / P.NTm]) { P.sflag[gt] = 0; activate(P, buf, gt, 0); }
+        if (P.consume[gt / P.NTm]) { P.sflag[gt] = 0; activate(P, k % 3, k & 1, gt, 0); }
         else P.slist2[atomicAdd(&s_keep, 1)] = gt;
     }
     __syncthreads();
     for (int i = threadIdx.x; i < s_keep; i += blockDim.x) P.slist[i] = P.slist2[i];
     if (threadIdx.x == 0) P.ctr->scount = s_keep;
 }
-__global__ void k_touched_to_active(DevParams P, int buf) {
+__global__ void k_touched_to_active(DevParams P, int k) {
     const int n = P.ctr->tcount;
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) activate(P, buf, P.tlist[i], 0);
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) activate(P, k % 3, k & 1, P.tlist[i], 0);
 }
-__global__ void k_activate_list(DevParams P, int buf, const int *tiles, int n) {
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) activate(P, buf, tiles[i], 0);
-}
-// Tile-level ordering (block fast marching): of the queued tiles only those whose incoming
-// value is within `delta` of the smallest one are released to the next relax launch; the rest
-// wait (their inputs are still going to improve).  delta = +inf degenerates to plain FIM.
-// One workgroup; also recycles the list counters.
-__global__ __launch_bounds__(1024) void k_triage(DevParams P, int cur, float delta) {
-    __shared__ int s_min;
-    const int nb = cur ^ 1;
-    const int n = P.ctr->ncand[cur];
-    if (threadIdx.x == 0) { P.ctr->nready = 0; P.ctr->ncand[nb] = 0; s_min = INFBITS; }
-    __syncthreads();
-    int lmin = INFBITS;
-    for (int i = threadIdx.x; i < n; i += blockDim.x) lmin = min(lmin, P.prio[P.cand[cur * P.NT + i]]);
-    if (lmin != INFBITS) atomicMin(&s_min, lmin);
-    __syncthreads();
-    const float theta = __int_as_float(s_min) + delta;
-    for (int i = threadIdx.x; i < n; i += blockDim.x) {
-        const int gt = P.cand[cur * P.NT + i];
-        if (!(__int_as_float(P.prio[gt]) > theta)) {
-            P.ready[atomicAdd(&P.ctr->nready, 1)] = gt;
-            P.queued[gt] = 0;
-            P.prio[gt] = INFBITS;
-        } else {
-            P.cand[nb * P.NT + atomicAdd(&P.ctr->ncand[nb], 1)] = gt;
-        }
-    }
+__global__ void k_activate_list(DevParams P, int k, const int *tiles, int n) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) activate(P, k % 3, k & 1, tiles[i], 0);
 }
 // mean traversable cost of a raster (sets the default ordering band)
 __global__ void k_cost_stats(const uint8_t *cm, size_t n, int thr, unsigned long long *out) {
@@ -545,7 +598,7 @@ struct Engine {
     std::vector<MapState> maps;
     std::vector<PatchRect> pending;
     std::vector<uint64_t> upd_pending;   // per map
-    int buf = 0;                     // candidate list the next triage reads
+    int buf = 0;                     // index k of the next relax launch within this step
     int grid_relax = 512;
     int max_iters = 4 * T;
     float delta_abs = -1.0f;         // ordering band; < 0: delta_scale * T * mean traversable cost
@@ -566,9 +619,9 @@ struct Engine {
 
 void Engine::release() {
     if (!allocated) return;
-    hipFree(P.G); hipFree(P.Gprev); hipFree(P.cost); hipFree(P.goal); hipFree(P.cand); hipFree(P.ready); hipFree(P.queued); hipFree(P.prio);
+    hipFree(P.G); hipFree(P.Gprev); hipFree(P.cost); hipFree(P.goal); hipFree(P.cand); hipFree(P.queued); hipFree(P.prio);
     hipFree(P.touched); hipFree(P.tlist); hipFree(P.sflag); hipFree(P.slist); hipFree(P.slist2);
-    hipFree(P.mark); hipFree(P.num_updated); hipFree(P.consume); hipFree(P.ctr);
+    hipFree(P.mark); hipFree(P.num_updated); hipFree(P.consume); hipFree(P.lmax); hipFree(P.ctr);
     hipFree(d_scratch);
     allocated = false;
 }
@@ -595,10 +648,9 @@ int Engine::alloc(int width, int length) {
     HIPCHK(hipMalloc(&P.Gprev, gbytes));
     HIPCHK(hipMalloc(&P.cost, P.cstride * nmaps));
     HIPCHK(hipMalloc(&P.goal, sizeof(int) * 2 * nmaps));
-    HIPCHK(hipMalloc(&P.cand, sizeof(int) * 2 * P.NT));
-    HIPCHK(hipMalloc(&P.ready, sizeof(int) * P.NT));
-    HIPCHK(hipMalloc(&P.queued, sizeof(int) * P.NT));
-    HIPCHK(hipMalloc(&P.prio, sizeof(int) * P.NT));
+    HIPCHK(hipMalloc(&P.cand, sizeof(int) * 3 * P.NT));
+    HIPCHK(hipMalloc(&P.queued, sizeof(int) * 2 * P.NT));
+    HIPCHK(hipMalloc(&P.prio, sizeof(int) * 2 * P.NT));
     HIPCHK(hipMalloc(&P.touched, sizeof(int) * P.NT));
     HIPCHK(hipMalloc(&P.tlist, sizeof(int) * P.NT));
     HIPCHK(hipMalloc(&P.sflag, sizeof(int) * P.NT));
@@ -607,11 +659,12 @@ int Engine::alloc(int width, int length) {
     HIPCHK(hipMalloc(&P.mark, sizeof(unsigned int) * P.mstride * nmaps));
     HIPCHK(hipMalloc(&P.num_updated, sizeof(unsigned int) * nmaps));
     HIPCHK(hipMalloc(&P.consume, sizeof(int) * nmaps));
+    HIPCHK(hipMalloc(&P.lmax, sizeof(int) * LMAX));
     HIPCHK(hipMalloc(&P.ctr, sizeof(DevCounters)));
     HIPCHK(hipMalloc(&d_scratch, sizeof(int) * (4 * nmaps + 4)));
     allocated = true;
-    HIPCHK(hipMemsetAsync(P.queued, 0, sizeof(int) * P.NT, stream));
-    k_fill<<<64, 256, 0, stream>>>(reinterpret_cast<float *>(P.prio), (size_t)P.NT, INFINITY);
+    HIPCHK(hipMemsetAsync(P.queued, 0, sizeof(int) * 2 * P.NT, stream));
+    k_fill<<<64, 256, 0, stream>>>(reinterpret_cast<float *>(P.prio), (size_t)2 * P.NT, INFINITY);
     HIPCHK(hipMemsetAsync(P.touched, 0, sizeof(int) * P.NT, stream));
     HIPCHK(hipMemsetAsync(P.sflag, 0, sizeof(int) * P.NT, stream));
     HIPCHK(hipMemsetAsync(P.mark, 0, sizeof(unsigned int) * P.mstride * nmaps, stream));
@@ -632,8 +685,7 @@ int Engine::launch_relax(int mode) {
     const dim3 g(grid_relax), b(NTHR);
     // invalidation is order-free; lowering releases tiles in bands of `delta`
     const float delta = (mode == MODE_RAISE) ? INFINITY : (delta_abs >= 0.0f ? delta_abs : delta_scale * T * mean_cost);
-    k_triage<<<1, 1024, 0, stream>>>(P, buf, delta);
-#define UFM_LAUNCH(A, M) k_relax<A, M><<<g, b, 0, stream>>>(P, buf ^ 1, max_iters)
+#define UFM_LAUNCH(A, M) k_relax<A, M><<<g, b, 0, stream>>>(P, buf, delta, max_iters)
     if (mode == MODE_LOWER) {
         if (algo == UFM_ALGO_FD) UFM_LAUNCH(UFM_ALGO_FD, MODE_LOWER);
         else if (algo == UFM_ALGO_SG) UFM_LAUNCH(UFM_ALGO_SG, MODE_LOWER);
@@ -644,7 +696,7 @@ int Engine::launch_relax(int mode) {
         else UFM_LAUNCH(UFM_ALGO_DFM, MODE_RAISE);
     }
 #undef UFM_LAUNCH
-    buf ^= 1;
+    ++buf;
     return UFM_OK;
 }
 
@@ -679,7 +731,7 @@ int Engine::run_phase(int mode, uint32_t *launches, float *kernel_ms) {
                 HIPCHK(hipEventElapsedTime(&ms, ev[2 * k], ev[2 * k + 1]));
                 *kernel_ms += ms;
             }
-        const int active = h_ctr->ncand[buf];
+        const int active = h_ctr->cnt[buf % 3];
         if (active == 0) return UFM_OK;
         if (total > cap) return UFM_ERR_NOT_CONVERGED;
         batch = batch_fixed > 0 ? batch_fixed : (active > 256 ? 16 : (active > 32 ? 8 : 4));
@@ -704,9 +756,10 @@ int Engine::step(ufm_stats *out) {
     ufm_stats st{};
     const auto t0 = std::chrono::steady_clock::now();
 
-    HIPCHK(hipMemsetAsync(P.ctr, 0, offsetof(DevCounters, scount), stream));                 // ncand, nready, tcount
+    HIPCHK(hipMemsetAsync(P.ctr, 0, offsetof(DevCounters, scount), stream));                 // cnt[3], tcount
     HIPCHK(hipMemsetAsync(&P.ctr->pad0, 0, sizeof(DevCounters) - offsetof(DevCounters, pad0), stream));
     buf = 0;
+    if (profiling) HIPCHK(hipMemsetAsync(P.lmax, 0, sizeof(int) * LMAX, stream));
 
     // classify maps: (re)initialise, propagate pending patches, or idle  (ReplannerBase.h:48-59)
     int n_init = 0, n_upd = 0;
@@ -797,6 +850,11 @@ int Engine::step(ufm_stats *out) {
         st.tile_visits = h_ctr->tile_visits;
         st.tile_iters = h_ctr->tile_iters;
         st.elem_evals = h_ctr->elem_evals;
+        if (profiling) {   // diagnostics: sum over launches of the slowest tile's sweep count
+            std::vector<int> lm(LMAX);
+            HIPCHK(hipMemcpy(lm.data(), P.lmax, sizeof(int) * LMAX, hipMemcpyDeviceToHost));
+            for (int v : lm) st.crit_sweeps += (uint64_t)v;
+        }
     }
     for (int m = 0; m < nmaps; ++m) maps[m].new_goal = maps[m].initialize_search = false;
     st.updated = updated;
