@@ -95,7 +95,10 @@ int ufm_read_map(ufm_t *p, uint8_t *host_map);
  * on them).  "delta": absolute width of the ordering band in cost units (< 0: automatic);
  * "delta_scale": band = scale * tile edge * mean traversable cost (default 1);
  * "max_iters": in-LDS sweep cap per tile visit; "batch": relax launches per host check
- * (0: adaptive); "grid": workgroups per relax launch. ---- */
+ * (0: adaptive); "grid": workgroups per relax launch.
+ * "focused" (default 1): honour the reference's end_condition -- propagate only as far as the
+ * start's key and keep the rest queued for later steps, like the reference's priority queue;
+ * 0 converges the whole field every step (every element then holds its final value). ---- */
 int ufm_set_param(ufm_t *p, const char *name, double value);
 
 /* ---- measurement hooks ---- */

@@ -79,6 +79,7 @@ def test_full_field_is_fixed_point_after_replans():
     cost = ufm_amd.synth.cost_map(seed, width, length)
     start, goal = ufm_amd.synth.start_goal(width, length)
     g = ufm_amd.Planner(ufm_amd.ALGO_FD, 1)
+    g.set_param("focused", 0)          # converge the whole field every step
     g.set_occupancy_threshold(1)
     g.set_map(cost)
     g.set_start(*start)
@@ -90,6 +91,7 @@ def test_full_field_is_fixed_point_after_replans():
         assert g.step() == 0
     inc = g.g()
     f = ufm_amd.Planner(ufm_amd.ALGO_FD, 1)
+    f.set_param("focused", 0)
     f.set_occupancy_threshold(1)
     f.set_map(_patched(cost, seed, width, length, 12))
     f.set_start(*start)
@@ -98,3 +100,39 @@ def test_full_field_is_fixed_point_after_replans():
     fresh = f.g()
     assert np.array_equal(inc, fresh)
     g.close(); f.close()
+
+
+@pytest.mark.parametrize("algo", ["FD", "SG", "DFM"])
+def test_focused_and_full_field_agree_below_the_start_key(algo):
+    """The default (focused) engine stops at the start's key like the reference's end_condition;
+    every element whose value is below that key must equal the fully converged field."""
+    width = length = 256
+    seed = 21
+    cost = ufm_amd.synth.cost_map(seed, width, length)
+    start, goal = ufm_amd.synth.start_goal(width, length)
+    ps = []
+    for focused in (1, 0):
+        p = ufm_amd.Planner(ALGOS[algo], 0)
+        p.set_param("focused", focused)
+        p.set_occupancy_threshold(1)
+        p.set_map(cost)
+        p.set_start(*start)
+        p.set_goal(*goal)
+        assert p.step() == 0
+        ps.append(p)
+    work = [0, 0]
+    for k, s, top, left, patch in ufm_amd.synth.replan_script(seed, width, length, n_patches=30):
+        for i, p in enumerate(ps):
+            p.patch_map(patch, top, left)
+            p.set_start(*s)
+            assert p.step() == 0
+            work[i] += p.stats.tile_visits
+        gf, gu = ps[0].g(), ps[1].g()
+        sx, sy = int(s[0]), int(s[1])
+        key = gu[sx, sy] if algo == "DFM" else max(gu[sx, sy], gu[sx + 1, sy], gu[sx, sy + 1], gu[sx + 1, sy + 1])
+        m = gu < key
+        assert m.sum() > 100
+        assert np.array_equal(gf[m], gu[m]), "replan %d: %d differ" % (k, int((gf[m] != gu[m]).sum()))
+    assert work[0] < work[1]          # focusing must save work
+    for p in ps:
+        p.close()

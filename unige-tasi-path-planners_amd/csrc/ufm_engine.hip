@@ -48,15 +48,24 @@ enum { MODE_LOWER = 0, MODE_RAISE = 1 };
 constexpr int LMAX = 8192;
 constexpr int INFBITS = 0x7F800000;   // +inf as int: non-negative floats order like their bits
 
+// Two work queues: Q_LOWER (value propagation, ordered by value) and Q_RAISE (invalidation,
+// keyed by the value an element had before it lost its support).  Entries that lie beyond the
+// current bound (the start's key, D*-Lite's end condition) stay queued across steps -- the
+// counterpart of the reference's persistent priority queue.
+enum { Q_LOWER = 0, Q_RAISE = 1 };
+
 struct DevCounters {
-    int cnt[3];                 // candidate-list lengths (ring of three, see k_relax)
+    int cnt[2][3];              // [queue][ring]: candidate-list lengths (ring of three, see k_relax)
+    int rel[2][3];              // [queue][ring]: tiles released (relaxed) by the launch that read the list
     int tcount;                 // touched-list length
     int scount;                 // pending-seed-list length (survives steps)
-    int pad0;
     unsigned long long expanded;
     unsigned long long tile_visits;
     unsigned long long tile_iters;
     unsigned long long elem_evals;
+    int qmin[2];                // k_queue_min: smallest priority queued
+    float rbound;               // invalidation bound computed on the device (k_prepare_bound / k_check)
+    int done;                   // k_check: both queues drained below the start's key
 };
 
 struct DevParams {
@@ -64,9 +73,12 @@ struct DevParams {
     float *Gprev;               // snapshot of a tile at its first touch in a step
     uint8_t *cost;              // [nmaps][L][W]
     int *goal;                  // [nmaps][2]
-    int *cand;                  // [3][NT] queued tiles (global tile ids), ring of three lists
-    int *queued;                // [2][NT] tile is in the candidate list of that launch parity
-    int *prio;                  // [2][NT] float bits: smallest value that entered the tile since its last visit
+    int *cand;                  // [2 queues][3][NT] queued tiles (global tile ids), ring of three lists
+    int *queued;                // [2 queues][2][NT] tile is in the candidate list of that launch parity
+    int *prio;                  // [2 queues][2][NT] float bits: smallest value that entered the tile since its last visit
+    int *start;                 // [nmaps][4] start elements (linear index in the map, -1 unused)
+    float *bnd;                 // [nmaps] k_start_bound output
+    int focused;                // honour the reference's end condition (stop at the start's key)
     int *touched;               // [NT]
     int *tlist;                 // [NT]
     int *sflag;                 // [NT] pending seeds (from patches)
@@ -87,13 +99,28 @@ struct DevParams {
     size_t mstride;             // words per map in mark
 };
 
-// queue tile gt for the launch that reads list `lst` / priority parity `par`
-__device__ __forceinline__ void activate(const DevParams &P, int lst, int par, int gt, int pbits) {
-    atomicMin(&P.prio[par * P.NT + gt], pbits);
-    if (atomicExch(&P.queued[par * P.NT + gt], 1) == 0) {
-        const int k = atomicAdd(&P.ctr->cnt[lst], 1);
-        P.cand[lst * P.NT + k] = gt;
+// queue tile gt in queue qz for the launch that reads list `lst` / priority parity `par`
+__device__ __forceinline__ void activate(const DevParams &P, int qz, int lst, int par, int gt, int pbits) {
+    atomicMin(&P.prio[(qz * 2 + par) * P.NT + gt], pbits);
+    if (atomicExch(&P.queued[(qz * 2 + par) * P.NT + gt], 1) == 0) {
+        const int k = atomicAdd(&P.ctr->cnt[qz][lst], 1);
+        P.cand[(qz * 3 + lst) * P.NT + k] = gt;
     }
+}
+// D*-Lite end condition as a bound on useful work (FieldDPlanner_impl.h:225-256,
+// ShiftedGridPlanner_impl.h:355-386, DynamicFastMarching_impl.h:315-320): the largest key
+// among the start elements that have been reached; +inf while none has.
+__device__ __forceinline__ float start_bound(const DevParams &P, int m) {
+    float b = 0.0f;
+    const float *Gm = P.G + (size_t)m * P.gstride;
+    for (int i = 0; i < 4; ++i) {
+        const int e = P.start[4 * m + i];
+        if (e < 0) continue;
+        const int x = e / P.EY, y = e - x * P.EY;
+        const float g = __hip_atomic_load(&Gm[(size_t)(x + 1) * P.pitch + (y + GPAD)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (g < INFINITY) b = fmaxf(b, g);
+    }
+    return b > 0.0f ? b : INFINITY;
 }
 
 // ---- update operators -------------------------------------------------------
@@ -255,7 +282,7 @@ __device__ __forceinline__ float cell_cost(const DevParams &P, const uint8_t *cm
 //     written back, and the neighbours whose halo changed are queued with the smallest changed
 //     value as priority.
 template <int ALGO, int MODE>
-__global__ __launch_bounds__(NTHR) void k_relax(DevParams P, int k, float delta, int max_sweeps) {
+__global__ __launch_bounds__(NTHR) void k_relax(DevParams P, int k, float delta, float rbound, int max_sweeps) {
     __shared__ float Gs[(T + 2) * GP];
     __shared__ float Cs[(T + 1) * CP];
     __shared__ int s_wake[16];  // per wave: bit j = patch j of the wave has new inputs
@@ -269,10 +296,14 @@ __global__ __launch_bounds__(NTHR) void k_relax(DevParams P, int k, float delta,
     const int q = lane & 3, nd = lane >> 2;                    // quad lane, node within the 4x4 patch
     const int wr = w >> 2, wc = w & 3;                         // the wave's 8x8 region = 2x2 patches
     const int io_r = tid >> 5, io_c = tid & 31;                // HBM mapping
+    constexpr int Q = (MODE == MODE_LOWER) ? Q_LOWER : Q_RAISE;
     const int r = k % 3, rn = (k + 1) % 3, rz = (k + 2) % 3, pc = k & 1, pn = pc ^ 1;
-    const int n = P.ctr->cnt[r];
-    if (blockIdx.x == 0 && tid == 0) P.ctr->cnt[rz] = 0;
+    const int n = P.ctr->cnt[Q][r];
+    if (blockIdx.x == 0 && tid == 0) { P.ctr->cnt[Q][rz] = 0; P.ctr->rel[Q][rz] = 0; }
     if (n == 0) return;
+    const int *cand = P.cand + (size_t)(Q * 3 + r) * P.NT;
+    int *prio = P.prio + (size_t)(Q * 2 + pc) * P.NT;
+    int *queued = P.queued + (size_t)(Q * 2 + pc) * P.NT;
     constexpr int CROWS = (ALGO == UFM_ALGO_DFM) ? T : T + 1;
     constexpr int COFF = (ALGO == UFM_ALGO_DFM) ? 0 : 1;
 
@@ -280,7 +311,7 @@ __global__ __launch_bounds__(NTHR) void k_relax(DevParams P, int k, float delta,
     __syncthreads();
     {
         int lmin = INFBITS;
-        for (int i = tid; i < n; i += NTHR) lmin = min(lmin, P.prio[pc * P.NT + P.cand[r * P.NT + i]]);
+        for (int i = tid; i < n; i += NTHR) lmin = min(lmin, prio[cand[i]]);
         if (lmin != INFBITS) atomicMin(&s_min, lmin);
     }
     __syncthreads();
@@ -298,15 +329,25 @@ __global__ __launch_bounds__(NTHR) void k_relax(DevParams P, int k, float delta,
     const int colour = ((nd >> 2) & 1) | ((nd & 1) << 1);
 
     for (int i = blockIdx.x; i < n; i += gridDim.x) {
-        const int gt = P.cand[r * P.NT + i];
-        const int pbits = P.prio[pc * P.NT + gt];
+        const int gt = cand[i];
+        const int pbits = prio[gt];
+        const int m = gt / P.NTm, t = gt - m * P.NTm;
+        // lowering: release within the ordering band and below the start's key (end condition);
+        // invalidation: release below the bound the host derived from the start's key
+        bool release;
+        if (MODE == MODE_LOWER) {
+            const float B = P.focused ? start_bound(P, m) : INFINITY;
+            release = !(__int_as_float(pbits) > theta) && (__int_as_float(pbits) < B || B == INFINITY);
+        } else {
+            release = !(__int_as_float(pbits) > (rbound < 0.0f ? P.ctr->rbound : rbound));
+        }
         __syncthreads();                                   // everyone holds pbits; LDS of the previous tile is free
-        if (tid == 0) { P.queued[pc * P.NT + gt] = 0; P.prio[pc * P.NT + gt] = INFBITS; }
-        if (__int_as_float(pbits) > theta) {               // not yet: carry over
-            if (tid == 0) activate(P, rn, pn, gt, pbits);
+        if (tid == 0) { queued[gt] = 0; prio[gt] = INFBITS; }
+        if (!release) {                                    // not yet: carry over
+            if (tid == 0) activate(P, Q, rn, pn, gt, pbits);
             continue;
         }
-        const int m = gt / P.NTm, t = gt - m * P.NTm;
+        if (tid == 0) atomicAdd(&P.ctr->rel[Q][r], 1);
         const int tx = t / P.TY, ty = t - tx * P.TY;
         const int x0 = tx * T, y0 = ty * T;
         float *Gm = P.G + (size_t)m * P.gstride;
@@ -445,8 +486,9 @@ __global__ __launch_bounds__(NTHR) void k_relax(DevParams P, int k, float delta,
         const float gf = Gs[(io_r + 1) * GP + io_c + 1];
         if (gf != gl0) {
             Gm[gidx] = gf;
-            // priority handed to a neighbour: the new value (lowering); invalidations are unordered
-            const int pb = (MODE == MODE_LOWER) ? __float_as_int(gf) : 0;
+            // priority handed to a neighbour: the new value (lowering) / the value that was
+            // invalidated (raising: the reference's key of an under-consistent element, min(g,rhs) = g)
+            const int pb = __float_as_int((MODE == MODE_LOWER) ? gf : gl0);
             const int er = (io_r == 0) ? -1 : ((io_r == T - 1) ? 1 : 0);
             const int ec = (io_c == 0) ? -1 : ((io_c == T - 1) ? 1 : 0);
             if (!conv) atomicMin(&s_bmin[4], pb);
@@ -458,14 +500,14 @@ __global__ __launch_bounds__(NTHR) void k_relax(DevParams P, int k, float delta,
         if (tid < 9) {
             const int dr = tid / 3 - 1, dc = tid % 3 - 1;
             if (tid == 4) {
-                if (!conv) activate(P, rn, pn, gt, min(s_bmin[4], INFBITS - 1));   // sweep cap hit: come back
+                if (!conv) activate(P, Q, rn, pn, gt, min(s_bmin[4], INFBITS - 1));   // sweep cap hit: come back
                 atomicMax(&P.lmax[k & (LMAX - 1)], s_misc[3]);
                 atomicAdd(&P.ctr->tile_visits, 1ull);
                 atomicAdd(&P.ctr->tile_iters, (unsigned long long)s_misc[3]);
                 atomicAdd(&P.ctr->elem_evals, 16ull * (unsigned long long)s_misc[2]);
             } else if (s_bmin[tid] != INFBITS) {
                 const int ntx = tx + dr, nty = ty + dc;
-                if (ntx >= 0 && ntx < P.TX && nty >= 0 && nty < P.TY) activate(P, rn, pn, m * P.NTm + ntx * P.TY + nty, s_bmin[tid]);
+                if (ntx >= 0 && ntx < P.TX && nty >= 0 && nty < P.TY) activate(P, Q, rn, pn, m * P.NTm + ntx * P.TY + nty, s_bmin[tid]);
             }
         }
     }
@@ -512,26 +554,74 @@ __global__ void k_clear_marks(DevParams P, int m, int x, int y, int w, int h) {
     P.mark[(size_t)m * P.mstride + (el >> 5)] = 0u;
 }
 // pending seeds of consuming maps -> candidate list of launch k; others stay pending. One block.
-__global__ void k_seeds_to_active(DevParams P, int k) {
+__global__ void k_seeds_to_active(DevParams P, int qz, int k) {
     __shared__ int s_keep;
     if (threadIdx.x == 0) s_keep = 0;
     __syncthreads();
     const int n = P.ctr->scount;
     for (int i = threadIdx.x; i < n; i += blockDim.x) {
         const int gt = P.slist[i];
-        if (P.consume[gt / P.NTm]) { P.sflag[gt] = 0; activate(P, k % 3, k & 1, gt, 0); }
+        if (P.consume[gt / P.NTm]) { P.sflag[gt] = 0; activate(P, qz, k % 3, k & 1, gt, 0); }
         else P.slist2[atomicAdd(&s_keep, 1)] = gt;
     }
     __syncthreads();
     for (int i = threadIdx.x; i < s_keep; i += blockDim.x) P.slist[i] = P.slist2[i];
     if (threadIdx.x == 0) P.ctr->scount = s_keep;
 }
-__global__ void k_touched_to_active(DevParams P, int k) {
+__global__ void k_touched_to_active(DevParams P, int qz, int k) {
     const int n = P.ctr->tcount;
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) activate(P, k % 3, k & 1, P.tlist[i], 0);
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) activate(P, qz, k % 3, k & 1, P.tlist[i], 0);
 }
-__global__ void k_activate_list(DevParams P, int k, const int *tiles, int n) {
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) activate(P, k % 3, k & 1, tiles[i], 0);
+__global__ void k_activate_list(DevParams P, int qz, int k, const int *tiles, int n) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) activate(P, qz, k % 3, k & 1, tiles[i], 0);
+}
+// smallest priority waiting in queue qz (list of launch k); one workgroup
+__global__ void k_queue_min(DevParams P, int qz, int k) {
+    __shared__ int s_m;
+    if (threadIdx.x == 0) s_m = INFBITS;
+    __syncthreads();
+    const int n = P.ctr->cnt[qz][k % 3];
+    int lmin = INFBITS;
+    for (int i = threadIdx.x; i < n; i += blockDim.x)
+        lmin = min(lmin, P.prio[(size_t)(qz * 2 + (k & 1)) * P.NT + P.cand[(size_t)(qz * 3 + k % 3) * P.NT + i]]);
+    if (lmin != INFBITS) atomicMin(&s_m, lmin);
+    __syncthreads();
+    if (threadIdx.x == 0) P.ctr->qmin[qz] = s_m;
+}
+// invalidation bound for this step: the current start key plus one ordering band
+__global__ void k_prepare_bound(DevParams P, float margin) {
+    if (threadIdx.x || blockIdx.x) return;
+    float b = 0.0f;
+    for (int m = 0; m < P.nmaps; ++m) b = fmaxf(b, start_bound(P, m));
+    P.ctr->rbound = P.focused ? b + margin : INFINITY;
+    P.ctr->done = 0;
+}
+// After a blind batch of invalidation + lowering launches: are both queues drained below the
+// start's key, and did the invalidation bound reach the key the start ended up with?
+// kr / kl: index of the next launch of the raise / lower queue.  One workgroup.
+__global__ void k_check(DevParams P, int kr, int kl, float margin) {
+    __shared__ int s_m;
+    if (threadIdx.x == 0) s_m = INFBITS;
+    __syncthreads();
+    const int n = P.ctr->cnt[Q_RAISE][kr % 3];
+    int lmin = INFBITS;
+    for (int i = threadIdx.x; i < n; i += blockDim.x)
+        lmin = min(lmin, P.prio[(size_t)(Q_RAISE * 2 + (kr & 1)) * P.NT + P.cand[(size_t)(Q_RAISE * 3 + kr % 3) * P.NT + i]]);
+    if (lmin != INFBITS) atomicMin(&s_m, lmin);
+    __syncthreads();
+    if (threadIdx.x) return;
+    float bnew = 0.0f;
+    for (int m = 0; m < P.nmaps; ++m) bnew = fmaxf(bnew, start_bound(P, m));
+    const bool raise_done = P.ctr->cnt[Q_RAISE][kr % 3] == 0 || P.ctr->rel[Q_RAISE][(kr + 2) % 3] == 0;
+    const bool lower_done = P.ctr->cnt[Q_LOWER][kl % 3] == 0 || P.ctr->rel[Q_LOWER][(kl + 2) % 3] == 0;
+    const bool again = P.focused && (__int_as_float(s_m) < bnew);
+    if (again) P.ctr->rbound = fmaxf(bnew, P.ctr->rbound) + margin;
+    P.ctr->qmin[Q_RAISE] = s_m;
+    P.ctr->done = (raise_done && lower_done && !again) ? 1 : 0;
+}
+__global__ void k_start_bound(DevParams P) {
+    const int m = blockIdx.x * blockDim.x + threadIdx.x;
+    if (m < P.nmaps) P.bnd[m] = start_bound(P, m);
 }
 // mean traversable cost of a raster (sets the default ordering band)
 __global__ void k_cost_stats(const uint8_t *cm, size_t n, int thr, unsigned long long *out) {
@@ -544,7 +634,8 @@ __global__ void k_cost_stats(const uint8_t *cm, size_t n, int thr, unsigned long
     if ((threadIdx.x & 63) == 0) { atomicAdd(&out[0], s); atomicAdd(&out[1], c); }
 }
 // count elements whose G differs from the snapshot taken at first touch; release the tiles
-__global__ __launch_bounds__(NTHR) void k_finalize(DevParams P) {
+__global__ __launch_bounds__(NTHR) void k_finalize(DevParams P, int only_if_done) {
+    if (only_if_done && !P.ctr->done) return;
     const int n = P.ctr->tcount;
     const int io_r = threadIdx.x >> 5, io_c = threadIdx.x & 31;
     for (int i = blockIdx.x; i < n; i += gridDim.x) {
@@ -576,6 +667,7 @@ struct MapState {
     bool new_goal = false;           // :151
     bool new_start = false;          // :152
     bool have_map = false;           // !initialize_graph :148
+    bool start_set = false;
     float start_x = 0, start_y = 0, goal_x = 0, goal_y = 0;
     int goal_ex = 0, goal_ey = 0;    // Node()/Cell() of the goal
     bool goal_elem_valid = false;
@@ -598,7 +690,10 @@ struct Engine {
     std::vector<MapState> maps;
     std::vector<PatchRect> pending;
     std::vector<uint64_t> upd_pending;   // per map
-    int buf = 0;                     // index k of the next relax launch within this step
+    int iter[2] = {0, 0};            // index k of the next relax launch of each queue (never reset: the queues persist)
+    bool focused = true;             // stop at the start's key like the reference (end_condition)
+    float *h_bnd = nullptr;          // pinned [nmaps]
+    int hist_raise = 3, hist_lower = 4;   // blind batch sizes of the replan fast path
     int grid_relax = 512;
     int max_iters = 4 * T;
     float delta_abs = -1.0f;         // ordering band; < 0: delta_scale * T * mean traversable cost
@@ -611,15 +706,17 @@ struct Engine {
 
     int alloc(int width, int length);
     void release();
-    int launch_relax(int mode);
-    int run_phase(int mode, uint32_t *launches, float *kernel_ms);
+    int launch_relax(int mode, float rbound);
+    int run_phase(int mode, float rbound, uint32_t *launches, float *kernel_ms);
+    int reset_queues();
+    int read_bounds(float *bmax);
     int step(ufm_stats *out);
     int patch(int m, const uint8_t *dev_patch, int x, int y, int w, int h);
 };
 
 void Engine::release() {
     if (!allocated) return;
-    hipFree(P.G); hipFree(P.Gprev); hipFree(P.cost); hipFree(P.goal); hipFree(P.cand); hipFree(P.queued); hipFree(P.prio);
+    hipFree(P.G); hipFree(P.Gprev); hipFree(P.cost); hipFree(P.goal); hipFree(P.cand); hipFree(P.queued); hipFree(P.prio); hipFree(P.start); hipFree(P.bnd);
     hipFree(P.touched); hipFree(P.tlist); hipFree(P.sflag); hipFree(P.slist); hipFree(P.slist2);
     hipFree(P.mark); hipFree(P.num_updated); hipFree(P.consume); hipFree(P.lmax); hipFree(P.ctr);
     hipFree(d_scratch);
@@ -648,9 +745,12 @@ int Engine::alloc(int width, int length) {
     HIPCHK(hipMalloc(&P.Gprev, gbytes));
     HIPCHK(hipMalloc(&P.cost, P.cstride * nmaps));
     HIPCHK(hipMalloc(&P.goal, sizeof(int) * 2 * nmaps));
-    HIPCHK(hipMalloc(&P.cand, sizeof(int) * 3 * P.NT));
-    HIPCHK(hipMalloc(&P.queued, sizeof(int) * 2 * P.NT));
-    HIPCHK(hipMalloc(&P.prio, sizeof(int) * 2 * P.NT));
+    HIPCHK(hipMalloc(&P.cand, sizeof(int) * 6 * P.NT));
+    HIPCHK(hipMalloc(&P.queued, sizeof(int) * 4 * P.NT));
+    HIPCHK(hipMalloc(&P.prio, sizeof(int) * 4 * P.NT));
+    HIPCHK(hipMalloc(&P.start, sizeof(int) * 4 * nmaps));
+    HIPCHK(hipMalloc(&P.bnd, sizeof(float) * nmaps));
+    HIPCHK(hipMemsetAsync(P.start, 0xFF, sizeof(int) * 4 * nmaps, stream));
     HIPCHK(hipMalloc(&P.touched, sizeof(int) * P.NT));
     HIPCHK(hipMalloc(&P.tlist, sizeof(int) * P.NT));
     HIPCHK(hipMalloc(&P.sflag, sizeof(int) * P.NT));
@@ -663,29 +763,47 @@ int Engine::alloc(int width, int length) {
     HIPCHK(hipMalloc(&P.ctr, sizeof(DevCounters)));
     HIPCHK(hipMalloc(&d_scratch, sizeof(int) * (4 * nmaps + 4)));
     allocated = true;
-    HIPCHK(hipMemsetAsync(P.queued, 0, sizeof(int) * 2 * P.NT, stream));
-    k_fill<<<64, 256, 0, stream>>>(reinterpret_cast<float *>(P.prio), (size_t)2 * P.NT, INFINITY);
+    HIPCHK(hipMemsetAsync(P.ctr, 0, sizeof(DevCounters), stream));
+    { int rc = reset_queues(); if (rc != UFM_OK) return rc; }
     HIPCHK(hipMemsetAsync(P.touched, 0, sizeof(int) * P.NT, stream));
     HIPCHK(hipMemsetAsync(P.sflag, 0, sizeof(int) * P.NT, stream));
     HIPCHK(hipMemsetAsync(P.mark, 0, sizeof(unsigned int) * P.mstride * nmaps, stream));
     HIPCHK(hipMemsetAsync(P.num_updated, 0, sizeof(unsigned int) * nmaps, stream));
     HIPCHK(hipMemsetAsync(P.goal, 0xFF, sizeof(int) * 2 * nmaps, stream));
-    HIPCHK(hipMemsetAsync(P.ctr, 0, sizeof(DevCounters), stream));
     k_fill<<<1024, 256, 0, stream>>>(P.G, P.gstride * nmaps, INFINITY);
     k_fill<<<1024, 256, 0, stream>>>(P.Gprev, P.gstride * nmaps, INFINITY);
     HIPCHK(hipGetLastError());
-    buf = 0;
     pending.clear();
     upd_pending.assign(nmaps, 0);
     for (auto &ms : maps) { ms.have_map = false; ms.initialize_search = true; }
     return UFM_OK;
 }
 
-int Engine::launch_relax(int mode) {
+// drop every queued tile (full re-initialisation: nothing of the old search survives)
+int Engine::reset_queues() {
+    HIPCHK(hipMemsetAsync(P.queued, 0, sizeof(int) * 4 * P.NT, stream));
+    k_fill<<<64, 256, 0, stream>>>(reinterpret_cast<float *>(P.prio), (size_t)4 * P.NT, INFINITY);
+    HIPCHK(hipMemsetAsync(P.ctr->cnt, 0, sizeof(int) * 12, stream));   // cnt + rel
+    iter[0] = iter[1] = 0;
+    return UFM_OK;
+}
+// largest start key over the maps (+inf if some map's start is not reached yet)
+int Engine::read_bounds(float *bmax) {
+    k_start_bound<<<(nmaps + 63) / 64, 64, 0, stream>>>(P);
+    HIPCHK(hipMemcpyAsync(h_bnd, P.bnd, sizeof(float) * nmaps, hipMemcpyDeviceToHost, stream));
+    HIPCHK(hipStreamSynchronize(stream));
+    float b = 0.0f;
+    for (int m = 0; m < nmaps; ++m) b = std::fmax(b, h_bnd[m]);
+    *bmax = b;
+    return UFM_OK;
+}
+
+int Engine::launch_relax(int mode, float rbound) {
     const dim3 g(grid_relax), b(NTHR);
     // invalidation is order-free; lowering releases tiles in bands of `delta`
     const float delta = (mode == MODE_RAISE) ? INFINITY : (delta_abs >= 0.0f ? delta_abs : delta_scale * T * mean_cost);
-#define UFM_LAUNCH(A, M) k_relax<A, M><<<g, b, 0, stream>>>(P, buf, delta, max_iters)
+    const int q = (mode == MODE_LOWER) ? Q_LOWER : Q_RAISE;
+#define UFM_LAUNCH(A, M) k_relax<A, M><<<g, b, 0, stream>>>(P, iter[q], delta, rbound, max_iters)
     if (mode == MODE_LOWER) {
         if (algo == UFM_ALGO_FD) UFM_LAUNCH(UFM_ALGO_FD, MODE_LOWER);
         else if (algo == UFM_ALGO_SG) UFM_LAUNCH(UFM_ALGO_SG, MODE_LOWER);
@@ -696,14 +814,17 @@ int Engine::launch_relax(int mode) {
         else UFM_LAUNCH(UFM_ALGO_DFM, MODE_RAISE);
     }
 #undef UFM_LAUNCH
-    ++buf;
+    ++iter[q];
     return UFM_OK;
 }
 
 // Launch relax kernels until the active list runs dry.  The list lengths live on
 // the device; the host peeks at them once per batch of launches (an empty launch
 // costs a few microseconds, a host round trip more).
-int Engine::run_phase(int mode, uint32_t *launches, float *kernel_ms) {
+// A phase also ends when a launch released nothing: everything still queued lies beyond the bound
+// (the start's key) and stays queued for a later step.
+int Engine::run_phase(int mode, float rbound, uint32_t *launches, float *kernel_ms) {
+    const int q = (mode == MODE_LOWER) ? Q_LOWER : Q_RAISE;
     int batch = batch_fixed > 0 ? batch_fixed : 4;
     const long cap = 64L * (P.TX + P.TY) * T + 4096;   // generous bound on sweeps
     long total = 0;
@@ -717,7 +838,7 @@ int Engine::run_phase(int mode, uint32_t *launches, float *kernel_ms) {
                 }
                 HIPCHK(hipEventRecord(ev[2 * k], stream));
             }
-            launch_relax(mode);
+            launch_relax(mode, rbound);
             if (profiling) HIPCHK(hipEventRecord(ev[2 * k + 1], stream));
         }
         HIPCHK(hipGetLastError());
@@ -731,8 +852,9 @@ int Engine::run_phase(int mode, uint32_t *launches, float *kernel_ms) {
                 HIPCHK(hipEventElapsedTime(&ms, ev[2 * k], ev[2 * k + 1]));
                 *kernel_ms += ms;
             }
-        const int active = h_ctr->cnt[buf % 3];
+        const int active = h_ctr->cnt[q][iter[q] % 3];
         if (active == 0) return UFM_OK;
+        if (h_ctr->rel[q][(iter[q] + 2) % 3] == 0) return UFM_OK;   // the last launch released nothing
         if (total > cap) return UFM_ERR_NOT_CONVERGED;
         batch = batch_fixed > 0 ? batch_fixed : (active > 256 ? 16 : (active > 32 ? 8 : 4));
     }
@@ -756,14 +878,19 @@ int Engine::step(ufm_stats *out) {
     ufm_stats st{};
     const auto t0 = std::chrono::steady_clock::now();
 
-    HIPCHK(hipMemsetAsync(P.ctr, 0, offsetof(DevCounters, scount), stream));                 // cnt[3], tcount
-    HIPCHK(hipMemsetAsync(&P.ctr->pad0, 0, sizeof(DevCounters) - offsetof(DevCounters, pad0), stream));
-    buf = 0;
+    HIPCHK(hipMemsetAsync(&P.ctr->tcount, 0, sizeof(int), stream));
+    HIPCHK(hipMemsetAsync(&P.ctr->expanded, 0, 4 * sizeof(unsigned long long), stream));
     if (profiling) HIPCHK(hipMemsetAsync(P.lmax, 0, sizeof(int) * LMAX, stream));
+    P.focused = focused ? 1 : 0;
 
     // classify maps: (re)initialise, propagate pending patches, or idle  (ReplannerBase.h:48-59)
     int n_init = 0, n_upd = 0;
     int *consume = h_scratch, *init_tiles = h_scratch + nmaps, *goals = h_scratch + 2 * nmaps;
+    {   // a full re-initialisation drops whatever the old search left queued
+        bool all_init = true;
+        for (int m = 0; m < nmaps; ++m) all_init = all_init && (maps[m].initialize_search || maps[m].new_goal);
+        if (all_init) { int rc = reset_queues(); if (rc != UFM_OK) return rc; }
+    }
     for (int m = 0; m < nmaps; ++m) {
         MapState &ms = maps[m];
         consume[m] = 0;
@@ -786,8 +913,25 @@ int Engine::step(ufm_stats *out) {
         if (ms.initialize_search || ms.new_goal)
             HIPCHK(hipMemcpyAsync(P.goal + 2 * m, goals + 2 * m, 2 * sizeof(int), hipMemcpyHostToDevice, stream));
     }
+    {   // start elements: the 4 corners of the start cell (FD impl:9-13, Cell.cpp:48-60) / the start cell (DFM)
+        int *st_el = h_scratch + 5 * nmaps + 4;
+        for (int m = 0; m < nmaps; ++m) {
+            const MapState &ms = maps[m];
+            for (int i = 0; i < 4; ++i) st_el[4 * m + i] = -1;
+            if (!ms.start_set) continue;
+            const int cx = (int)std::roundf(ms.start_x), cy = (int)std::roundf(ms.start_y);
+            const int ncorner = (algo == UFM_ALGO_DFM) ? 1 : 4;
+            for (int i = 0; i < ncorner; ++i) {
+                const int ex = cx + (i & 1), ey = cy + (i >> 1);
+                if (ex >= 0 && ey >= 0 && ex < P.EX && ey < P.EY) st_el[4 * m + i] = ex * P.EY + ey;
+            }
+        }
+        HIPCHK(hipMemcpyAsync(P.start, st_el, sizeof(int) * 4 * nmaps, hipMemcpyHostToDevice, stream));
+    }
     uint64_t updated = 0;
     bool have_seeds = false;
+    bool fast_done = false;
+    const float band = (delta_abs >= 0.0f ? delta_abs : delta_scale * T * mean_cost);
     if (n_upd > 0 || n_init > 0) {
         HIPCHK(hipMemcpyAsync(P.consume, consume, sizeof(int) * nmaps, hipMemcpyHostToDevice, stream));
         // consume pending patch rectangles of the participating maps
@@ -800,10 +944,49 @@ int Engine::step(ufm_stats *out) {
         }
         pending.swap(keep);
     }
-    if (have_seeds) {
+    const auto t_seed = std::chrono::steady_clock::now();
+    if (have_seeds && n_init == 0 && n_upd > 0) {
+        // Replan fast path: one submission, one host round trip.  Seeds -> invalidation bound ->
+        // a blind batch of invalidation launches -> re-lower what they touched -> a blind batch of
+        // lowering launches -> device-side check -> finalise if the check says "done".  (An empty
+        // launch costs a few microseconds; a host round trip costs more.)  If the batches were too
+        // short the general adaptive loop below takes over.
+        k_seeds_to_active<<<1, 1024, 0, stream>>>(P, Q_RAISE, iter[Q_RAISE]);
+        k_prepare_bound<<<1, 64, 0, stream>>>(P, band);
+        const int nr = hist_raise + 2, nl = hist_lower + 2;
+        hipEvent_t e0 = nullptr, e1 = nullptr;
+        if (profiling) {
+            while (ev.size() < 2) { hipEvent_t a; HIPCHK(hipEventCreate(&a)); ev.push_back(a); }
+            e0 = ev[0]; e1 = ev[1];
+            HIPCHK(hipEventRecord(e0, stream));
+        }
+        for (int i = 0; i < nr; ++i) launch_relax(MODE_RAISE, -1.0f);
+        k_touched_to_active<<<64, 256, 0, stream>>>(P, Q_LOWER, iter[Q_LOWER]);
+        for (int i = 0; i < nl; ++i) launch_relax(MODE_LOWER, INFINITY);
+        if (profiling) HIPCHK(hipEventRecord(e1, stream));
+        k_check<<<1, 1024, 0, stream>>>(P, iter[Q_RAISE], iter[Q_LOWER], band);
+        k_finalize<<<grid_relax, NTHR, 0, stream>>>(P, 1);
+        HIPCHK(hipMemcpyAsync(h_ctr, P.ctr, sizeof(DevCounters), hipMemcpyDeviceToHost, stream));
+        HIPCHK(hipMemcpyAsync(h_scratch + 4 * nmaps, P.num_updated, sizeof(unsigned int) * nmaps, hipMemcpyDeviceToHost, stream));
+        HIPCHK(hipMemsetAsync(P.num_updated, 0, sizeof(unsigned int) * nmaps, stream));
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipStreamSynchronize(stream));
+        if (profiling) { float ms = 0; HIPCHK(hipEventElapsedTime(&ms, e0, e1)); st.kernel_ms += ms; }
+        const unsigned int *nu = reinterpret_cast<const unsigned int *>(h_scratch + 4 * nmaps);
+        for (int m = 0; m < nmaps; ++m) if (consume[m]) updated += nu[m];
+        st.raise_launches += (uint32_t)nr;
+        st.launches += (uint32_t)(nr + nl);
+        fast_done = h_ctr->done != 0;
+        // launches the batches actually needed (for the next step's batch sizes)
+        hist_raise = hist_raise > 1 ? hist_raise - 1 : 1;
+        hist_lower = hist_lower > 1 ? hist_lower - 1 : 1;
+        if (!fast_done) { hist_raise += 3; hist_lower += 3; }
+    } else if (have_seeds) {
         // num_nodes_updated (FD impl:138, DFM impl:109) of the participating maps
         HIPCHK(hipMemcpyAsync(h_scratch + 2 * nmaps + 2 * nmaps, P.num_updated, sizeof(unsigned int) * nmaps, hipMemcpyDeviceToHost, stream));
-        k_seeds_to_active<<<1, 1024, 0, stream>>>(P, buf);
+        // patches enter an existing field through the invalidation queue, a fresh one directly
+        const int sq = (n_upd > 0) ? Q_RAISE : Q_LOWER;
+        k_seeds_to_active<<<1, 1024, 0, stream>>>(P, sq, iter[sq]);
         HIPCHK(hipStreamSynchronize(stream));
         const unsigned int *nu = reinterpret_cast<const unsigned int *>(h_scratch + 4 * nmaps);
         for (int m = 0; m < nmaps; ++m) {
@@ -813,14 +996,6 @@ int Engine::step(ufm_stats *out) {
             HIPCHK(hipMemsetAsync(P.num_updated + m, 0, sizeof(unsigned int), stream));
         }
     }
-    // invalidation phase: only needed when patches are being propagated into an existing field
-    if (have_seeds && n_upd > 0) {
-        int rc = run_phase(MODE_RAISE, &st.raise_launches, &st.kernel_ms);
-        if (rc != UFM_OK) return rc;
-        st.launches += st.raise_launches;
-        // everything the raise phase touched must be re-lowered
-        k_touched_to_active<<<64, 256, 0, stream>>>(P, buf);
-    }
     if (n_init > 0) {
         int k = 0;
         for (int m = 0; m < nmaps; ++m) {
@@ -829,21 +1004,65 @@ int Engine::step(ufm_stats *out) {
         }
         if (k > 0) {
             HIPCHK(hipMemcpyAsync(d_scratch, init_tiles, sizeof(int) * k, hipMemcpyHostToDevice, stream));
-            k_activate_list<<<1, 64, 0, stream>>>(P, buf, d_scratch, k);
+            k_activate_list<<<1, 64, 0, stream>>>(P, Q_LOWER, iter[Q_LOWER], d_scratch, k);
         }
     }
-    HIPCHK(hipStreamSynchronize(stream));
-    const auto t1 = std::chrono::steady_clock::now();
-    st.u_ms = std::chrono::duration<float, std::milli>(t1 - t0).count();
-
     // ReplannerBase.h:65-69: plan() only if something was (re)initialised or updated
-    const bool do_plan = n_init > 0 || updated > 0 || (have_seeds && n_upd > 0);
+    const bool do_plan = (n_init > 0 || updated > 0 || (have_seeds && n_upd > 0)) && !fast_done;
+    const bool do_raise = have_seeds && n_upd > 0;
+    auto t1 = std::chrono::steady_clock::now();
+    double u_acc = std::chrono::duration<double, std::milli>(t1 - t0).count(), p_acc = 0.0;
     if (do_plan) {
-        uint32_t ll = 0;
-        int rc = run_phase(MODE_LOWER, &ll, &st.kernel_ms);
-        if (rc != UFM_OK) return rc;
-        st.launches += ll;
-        k_finalize<<<grid_relax, NTHR, 0, stream>>>(P);
+        // Invalidate, then lower, both only as far as the start's key (the reference's
+        // end_condition).  The invalidation bound must reach the key the start ends up with, which
+        // is only known afterwards: start from the current key plus one ordering band and repeat
+        // while invalidations below the new key are still queued.
+        float rbound = INFINITY;
+        if (focused && do_raise) {
+            if (h_ctr->rbound > 0.0f && n_init == 0 && n_upd > 0) {
+                rbound = h_ctr->rbound;      // continue from the fast path's (possibly enlarged) bound
+            } else {
+                float b0 = 0.0f;
+                int rc = read_bounds(&b0);
+                if (rc != UFM_OK) return rc;
+                rbound = b0 + band;
+            }
+        }
+        for (int round = 0; round < 64; ++round) {
+            const auto ta = std::chrono::steady_clock::now();
+            if (do_raise) {
+                uint32_t rl = 0;
+                int rc = run_phase(MODE_RAISE, rbound, &rl, &st.kernel_ms);
+                if (rc != UFM_OK) return rc;
+                st.raise_launches += rl;
+                st.launches += rl;
+                // everything invalidation touched must be re-lowered
+                k_touched_to_active<<<64, 256, 0, stream>>>(P, Q_LOWER, iter[Q_LOWER]);
+            }
+            const auto tb = std::chrono::steady_clock::now();
+            uint32_t ll = 0;
+            int rc = run_phase(MODE_LOWER, INFINITY, &ll, &st.kernel_ms);
+            if (rc != UFM_OK) return rc;
+            st.launches += ll;
+            bool again = false;
+            if (focused && do_raise) {
+                float bnew = 0.0f;
+                rc = read_bounds(&bnew);
+                if (rc != UFM_OK) return rc;
+                k_queue_min<<<1, 1024, 0, stream>>>(P, Q_RAISE, iter[Q_RAISE]);
+                HIPCHK(hipMemcpyAsync(h_ctr, P.ctr, sizeof(DevCounters), hipMemcpyDeviceToHost, stream));
+                HIPCHK(hipStreamSynchronize(stream));
+                float qm;
+                std::memcpy(&qm, &h_ctr->qmin[Q_RAISE], sizeof(float));
+                if (qm < bnew) { again = true; rbound = std::fmax(bnew, rbound) + band; }
+            }
+            const auto tc = std::chrono::steady_clock::now();
+            u_acc += std::chrono::duration<double, std::milli>(tb - ta).count();
+            p_acc += std::chrono::duration<double, std::milli>(tc - tb).count();
+            if (!again) break;
+        }
+        const auto td = std::chrono::steady_clock::now();
+        k_finalize<<<grid_relax, NTHR, 0, stream>>>(P, 0);
         HIPCHK(hipMemcpyAsync(h_ctr, P.ctr, sizeof(DevCounters), hipMemcpyDeviceToHost, stream));
         HIPCHK(hipStreamSynchronize(stream));
         st.expanded = h_ctr->expanded;
@@ -855,11 +1074,22 @@ int Engine::step(ufm_stats *out) {
             HIPCHK(hipMemcpy(lm.data(), P.lmax, sizeof(int) * LMAX, hipMemcpyDeviceToHost));
             for (int v : lm) st.crit_sweeps += (uint64_t)v;
         }
+        p_acc += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - td).count();
+    } else if (fast_done) {
+        st.expanded = h_ctr->expanded;
+        st.tile_visits = h_ctr->tile_visits;
+        st.tile_iters = h_ctr->tile_iters;
+        st.elem_evals = h_ctr->elem_evals;
+        const double dt = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_seed).count();
+        u_acc += 0.5 * dt;   // invalidation and lowering ran in one submission: split evenly
+        p_acc += 0.5 * dt;
+    } else {
+        HIPCHK(hipStreamSynchronize(stream));
     }
     for (int m = 0; m < nmaps; ++m) maps[m].new_goal = maps[m].initialize_search = false;
     st.updated = updated;
-    const auto t2 = std::chrono::steady_clock::now();
-    st.p_ms = std::chrono::duration<float, std::milli>(t2 - t1).count();
+    st.u_ms = (float)u_acc;   // seeding + invalidation (the reference's update())
+    st.p_ms = (float)p_acc;   // propagation + finalisation (the reference's plan())
     last = st;
     if (out) *out = st;
     return UFM_OK;
@@ -881,7 +1111,8 @@ int engine_create(Engine **out, int n_maps, int algo, int opt_lvl, int use_heuri
     e->grid_relax = prop.multiProcessorCount * 2;
     HIPCHK(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
     HIPCHK(hipHostMalloc(&e->h_ctr, sizeof(DevCounters)));
-    HIPCHK(hipHostMalloc(&e->h_scratch, sizeof(int) * (6 * n_maps + 4)));
+    HIPCHK(hipHostMalloc(&e->h_scratch, sizeof(int) * (9 * n_maps + 8)));
+    HIPCHK(hipHostMalloc(&e->h_bnd, sizeof(float) * n_maps));
     *out = e;
     return UFM_OK;
 }
@@ -896,6 +1127,7 @@ int engine_destroy(Engine *e) {
     if (e->h_patch) hipHostFree(e->h_patch);
     if (e->h_ctr) hipHostFree(e->h_ctr);
     if (e->h_scratch) hipHostFree(e->h_scratch);
+    if (e->h_bnd) hipHostFree(e->h_bnd);
     if (e->stream) hipStreamDestroy(e->stream);
     delete e;
     return UFM_OK;
@@ -1014,7 +1246,7 @@ int ufm_patch_map_device(ufm_t *p, const uint8_t *dev_patch, int x, int y, int w
 int ufm_set_start(ufm_t *p, float x, float y) {
     if (!p) return UFM_ERR_INVALID;
     MapState &ms = p->e->maps[0];
-    ms.start_x = x; ms.start_y = y; ms.new_start = true;   // ReplannerBase.h:94-97
+    ms.start_x = x; ms.start_y = y; ms.new_start = true; ms.start_set = true;   // ReplannerBase.h:94-97
     return UFM_OK;
 }
 int ufm_set_goal(ufm_t *p, float x, float y) { return p ? engine_set_goal(p->e, 0, x, y) : UFM_ERR_INVALID; }
@@ -1045,6 +1277,7 @@ int ufm_set_param(ufm_t *p, const char *name, double value) {
     else if (!std::strcmp(name, "max_iters")) e->max_iters = value < 1 ? 1 : (int)value;
     else if (!std::strcmp(name, "batch")) e->batch_fixed = (int)value;
     else if (!std::strcmp(name, "grid")) e->grid_relax = value < 1 ? 1 : (int)value;
+    else if (!std::strcmp(name, "focused")) e->focused = value != 0.0;
     else return UFM_ERR_INVALID;
     return UFM_OK;
 }
@@ -1077,7 +1310,7 @@ int ufm_batch_patch_map(ufm_batch_t *b, int i, const uint8_t *host_patch, int x,
 int ufm_batch_set_start(ufm_batch_t *b, int i, float x, float y) {
     if (!b || i < 0 || i >= b->e->nmaps) return UFM_ERR_INVALID;
     MapState &ms = b->e->maps[i];
-    ms.start_x = x; ms.start_y = y; ms.new_start = true;
+    ms.start_x = x; ms.start_y = y; ms.new_start = true; ms.start_set = true;
     return UFM_OK;
 }
 int ufm_batch_set_goal(ufm_batch_t *b, int i, float x, float y) { return b ? engine_set_goal(b->e, i, x, y) : UFM_ERR_INVALID; }
