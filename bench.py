@@ -99,31 +99,19 @@ def main():
     planner.set_occupancy_threshold(1)
     planner.set_profiling(not args.no_profile)
 
-    def episode():
-        cells = visits = launches = evals = 0
-        kms = 0.0
-        planner.set_map_device(d_cost.data_ptr(), size, size)
-        planner.reset()
-        planner.set_start(*start)
-        planner.set_goal(*goal)
-        assert planner.step() == 0
-        st = planner.stats
-        cells += st.expanded; visits += st.tile_visits; launches += st.launches; kms += st.kernel_ms; evals += st.elem_evals
-        for i, (k, s, top, left, _) in enumerate(script):
-            if dist is not None:
-                if rank == 0:
-                    d_recv.copy_(d_patches[i])
-                dist.broadcast(d_recv, src=0)
-                torch.cuda.current_stream().synchronize()
-                src = d_recv
-            else:
-                src = d_patches[i]
-            planner.patch_map_device(src.data_ptr(), top, left, psz, psz)
-            planner.set_start(*s)
-            assert planner.step() == 0
-            st = planner.stats
-            cells += st.expanded; visits += st.tile_visits; launches += st.launches; kms += st.kernel_ms; evals += st.elem_evals
-        return cells, visits, launches, kms, evals
+    ep = ufm_amd.episode
+    stream = ep.PatchStream(d_patches if rank == 0 else None, d_recv, dist=dist, rank=rank,
+                            sync=lambda: torch.cuda.current_stream().synchronize())
+    meta = [(k, s, top, left) for (k, s, top, left, _) in script]
+
+    def run_one():
+        return ep.run_episode(
+            planner,
+            set_map=lambda p: p.set_map_device(d_cost.data_ptr(), size, size),
+            start=start, goal=goal, script=meta, stream=stream,
+            apply_patch=lambda p, buf, top, left: p.patch_map_device(buf.data_ptr(), top, left, psz, psz),
+            read_stats=lambda p: {"cells": p.stats.expanded, "visits": p.stats.tile_visits, "launches": p.stats.launches,
+                                  "kernel_ms": p.stats.kernel_ms, "evals": p.stats.elem_evals})
 
     def barrier():
         torch.cuda.synchronize()
@@ -131,16 +119,8 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        episode()
-    barrier()
-    t0 = time.perf_counter()
-    tot = [0, 0, 0, 0.0, 0]
-    for _ in range(args.steps):
-        r = episode()
-        tot = [a + b for a, b in zip(tot, r)]
-    barrier()
-    dt = time.perf_counter() - t0
+    dt, per_step = ep.timed_episodes(run_one, args.steps, args.warmup, barrier)
+    tot = [sum(d[k] for d in per_step) for k in ("cells", "visits", "launches", "kernel_ms", "evals")]
 
     cells, visits, launches, kms, evals = tot
     if dist is not None:

@@ -1,0 +1,87 @@
+// A driver written against the reference's planner surface, following the call sequence of
+// Tests/Planners/FDSTAR/main.cpp:77-166 (without the FIFOs): construct, configure, plan, then a
+// few {patch_map, set_heuristic_multiplier, step, read the field around the start, set_start}
+// rounds, finally the `tof` dump over map.buckets.  It prints what it reads; the pytest that
+// builds and runs it compares the numbers with the Python binding / the oracle.
+//
+// usage: drop_in_driver <FD|SG|DFM> <size> <seed-dependent map file (raw uint8 size*size)> <n_patches> <patch file>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <memory>
+#include <string>
+#include <vector>
+
+#define NO_HEURISTIC
+#include "DynamicFastMarching.h"
+#include "FieldDPlanner.h"
+#include "ShiftedGridPlanner.h"
+
+template <typename Planner>
+int run(int size, const std::vector<uint8_t> &raster, int n_patches, const std::vector<uint8_t> &patches) {
+  std::shared_ptr<uint8_t> data(new uint8_t[(size_t)size * size], std::default_delete<uint8_t[]>());
+  std::memcpy(data.get(), raster.data(), raster.size());
+  Planner planner{};
+  typedef typename Planner::Map::ElemType Elem;
+  Position next_point(8.0f, 8.0f), goal((float)(size - 8), (float)(size - 8));
+  planner.reset();
+  planner.set_occupancy_threshold(1);
+  planner.set_heuristic_multiplier(1);
+  planner.set_map(data, size, size);
+  planner.set_start(next_point);
+  planner.set_goal(goal);
+  if (planner.step() != LOOP_OK) { std::printf("step failed %d\n", planner.last_error); return 2; }
+  const auto &map = planner.get_expanded_map();
+  const auto &grid = planner.get_grid();
+  std::printf("plan expanded %lu g_start %.9g cost_start %.1f\n", planner.num_nodes_expanded,
+              map.get_g(Elem((int)next_point.x, (int)next_point.y)), grid.get_cost(Cell(next_point)));
+  const int psz = 31;
+  for (int k = 0; k < n_patches; ++k) {
+    const uint8_t *rec = patches.data() + (size_t)k * (psz * psz + 16);
+    int32_t hdr[4];
+    std::memcpy(hdr, rec, 16);   // top, left, start_x, start_y
+    std::shared_ptr<uint8_t> patch(new uint8_t[psz * psz], std::default_delete<uint8_t[]>());
+    std::memcpy(patch.get(), rec + 16, psz * psz);
+    planner.patch_map(patch, hdr[0], hdr[1], psz, psz);
+    planner.set_heuristic_multiplier(1);
+    next_point = Position((float)hdr[2], (float)hdr[3]);
+    planner.set_start(next_point);
+    if (planner.step() != LOOP_OK) { std::printf("step failed %d\n", planner.last_error); return 2; }
+    const Node sn(next_point);
+    std::printf("replan %d updated %lu rhs_start %.9g interp %.9g consistent %d patched_cost %.1f\n", k,
+                planner.num_nodes_updated, map.get_rhs(Elem(sn.x, sn.y)), map.get_interp_rhs(sn),
+                (int)map.consistent(Elem(sn.x, sn.y)), grid.get_cost(Cell(hdr[0], hdr[1])));
+  }
+  // the `tof` dump (main.cpp:139-156)
+  const long long n = (long long)planner.map.size();
+  double sum = 0;
+  long long cnt = 0;
+  for (const auto &b : planner.map.buckets)
+    for (const auto &e : b) { sum += std::get<0>(e.second); ++cnt; (void)e.first.x; }
+  std::printf("dump size %lld iterated %lld sum_g %.6f\n", n, cnt, sum);
+  return 0;
+}
+
+int main(int argc, char **argv) {
+  if (argc < 6) { std::fprintf(stderr, "usage: %s <FD|SG|DFM> <size> <map.raw> <n_patches> <patches.raw>\n", argv[0]); return 1; }
+  const std::string algo = argv[1];
+  const int size = std::atoi(argv[2]), n_patches = std::atoi(argv[4]);
+  auto slurp = [](const char *path) {
+    std::vector<uint8_t> v;
+    if (FILE *f = std::fopen(path, "rb")) {
+      std::fseek(f, 0, SEEK_END); long n = std::ftell(f); std::fseek(f, 0, SEEK_SET);
+      v.resize((size_t)n);
+      if (std::fread(v.data(), 1, (size_t)n, f) != (size_t)n) v.clear();
+      std::fclose(f);
+    }
+    return v;
+  };
+  const std::vector<uint8_t> raster = slurp(argv[3]), patches = slurp(argv[5]);
+  if ((int)raster.size() != size * size) { std::fprintf(stderr, "bad map file\n"); return 1; }
+  try {
+    if (algo == "FD") return run<FieldDPlanner<1>>(size, raster, n_patches, patches);
+    if (algo == "SG") return run<ShiftedGridPlanner<2>>(size, raster, n_patches, patches);
+    if (algo == "DFM") return run<DFMPlanner<1>>(size, raster, n_patches, patches);
+  } catch (const std::exception &e) { std::fprintf(stderr, "error: %s\n", e.what()); return 3; }
+  return 1;
+}

@@ -1,0 +1,48 @@
+"""CPU: libufm.so loads and exports every entry point include/ufm.h declares.  No compute."""
+import ctypes
+import os
+import re
+
+import pytest
+
+import ufm_amd
+from ufm_amd_pkg import capi
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared():
+    txt = open(os.path.join(ROOT, "include", "ufm.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(ufm_[a-z_0-9]+)\s*\(", txt)))
+
+
+def test_header_and_binding_list_agree():
+    assert _declared() == sorted(capi.SYMBOLS)
+
+
+def test_library_exports_every_symbol():
+    if not os.path.exists(ufm_amd.library_path()):
+        ufm_amd.build_library()
+    lib = ctypes.CDLL(ufm_amd.library_path())
+    for name in _declared():
+        assert hasattr(lib, name), name
+
+
+def test_no_cpu_fallback():
+    """Without a GPU creating a planner must fail loudly (negative code -> UfmError), never fall
+    back to a CPU path.  With a GPU it simply succeeds."""
+    try:
+        p = ufm_amd.Planner(ufm_amd.ALGO_FD, 0)
+    except ufm_amd.UfmError as e:
+        assert "ufm_create" in str(e)
+        return
+    p.close()
+
+
+def test_bad_arguments_rejected():
+    lib = ufm_amd.load_library()
+    h = ctypes.c_void_p()
+    assert lib.ufm_create(ctypes.byref(h), 7, 0, 0, 0) == -22          # unknown planner family
+    assert lib.ufm_create(ctypes.byref(h), ufm_amd.ALGO_FD, 2, 0, 0) == -22   # only SG has level 2
+    assert lib.ufm_version().startswith(b"ufm-gfx950")

@@ -1,0 +1,75 @@
+"""The header-only C++ mirror of the reference planner surface (unige-tasi-path-planners_amd/include)
+compiles against include/ufm.h (CPU) and, on a GPU, a driver written like the reference's
+Tests/Planners/FDSTAR/main.cpp produces the same numbers as the C-ABI called from Python."""
+import os
+import re
+import struct
+import subprocess
+
+import numpy as np
+import pytest
+
+import ufm_amd
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PKG = os.path.join(ROOT, "unige-tasi-path-planners_amd")
+EXE = os.path.join(ROOT, "build", "drop_in_driver")
+
+
+def _build():
+    os.makedirs(os.path.dirname(EXE), exist_ok=True)
+    if not os.path.exists(ufm_amd.library_path()):
+        ufm_amd.build_library()
+    subprocess.check_call([
+        "g++", "-std=c++17", "-O1", "-Wall", "-Wextra", "-Werror", "-I" + os.path.join(ROOT, "include"),
+        "-I" + os.path.join(PKG, "include"), os.path.join(ROOT, "tests", "cpp", "drop_in_driver.cpp"),
+        "-o", EXE, "-L" + PKG, "-lufm", "-Wl,-rpath," + PKG])
+
+
+def test_driver_compiles_against_the_surface():
+    _build()
+    assert os.path.exists(EXE)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("algo", ["FD", "SG", "DFM"])
+def test_driver_matches_python_binding(tmp_path, algo):
+    _build()
+    size, seed, n = 160, 13, 4
+    cost = ufm_amd.synth.cost_map(seed, size, size)
+    script = list(ufm_amd.synth.replan_script(seed, size, size, n_patches=n))
+    (tmp_path / "map.raw").write_bytes(cost.tobytes())
+    with open(tmp_path / "patches.raw", "wb") as f:
+        for k, s, top, left, patch in script:
+            f.write(struct.pack("<4i", top, left, int(s[0]), int(s[1])))
+            f.write(patch.tobytes())
+    out = subprocess.check_output([EXE, algo, str(size), str(tmp_path / "map.raw"), str(n), str(tmp_path / "patches.raw")], text=True)
+    lines = out.strip().splitlines()
+
+    ids = {"FD": (ufm_amd.ALGO_FD, 1), "SG": (ufm_amd.ALGO_SG, 2), "DFM": (ufm_amd.ALGO_DFM, 1)}[algo]
+    p = ufm_amd.Planner(*ids)
+    p.reset(); p.set_occupancy_threshold(1); p.set_map(cost)
+    start, goal = ufm_amd.synth.start_goal(size, size)
+    p.set_start(*start); p.set_goal(*goal)
+    assert p.step() == 0
+    m = re.match(r"plan expanded (\d+) g_start (\S+) cost_start (\S+)", lines[0])
+    assert int(m.group(1)) == p.num_nodes_expanded
+    assert np.float32(m.group(2)) == p.g()[8, 8]
+    cur = cost.copy()
+    for i, (k, s, top, left, patch) in enumerate(script):
+        p.patch_map(patch, top, left); p.set_start(*s)
+        cur[top:top + 31, left:left + 31] = patch
+        assert p.step() == 0
+        m = re.match(r"replan (\d+) updated (\d+) rhs_start (\S+) interp (\S+) consistent (\d) patched_cost (\S+)", lines[1 + i])
+        assert int(m.group(2)) == p.num_nodes_updated
+        g = p.g()
+        sx, sy = int(s[0]), int(s[1])
+        assert np.float32(m.group(3)) == g[sx, sy]
+        if algo != "DFM":
+            assert np.float32(m.group(4)) == g[sx, sy]
+        assert float(m.group(6)) == float(cur[top, left])     # the host-side Graph mirror followed the patch
+    m = re.match(r"dump size (\d+) iterated (\d+) sum_g (\S+)", lines[-1])
+    g = p.g()
+    assert int(m.group(1)) == int(m.group(2)) == int(np.isfinite(g).sum())
+    assert abs(float(m.group(3)) - float(g[np.isfinite(g)].astype(np.float64).sum())) <= 1e-6 * float(m.group(3))
+    p.close()

@@ -12,3 +12,4 @@ from .capi import (  # noqa: F401
     UfmError, Planner, BatchPlanner, Stats, load_library, library_path, build_library,
 )
 from . import synth  # noqa: F401
+from . import episode  # noqa: F401

@@ -1,0 +1,70 @@
+"""One benchmark episode = full plan + N replans on one map instance, and its multi-rank form.
+
+Independent map instances shard across ranks (one process per GPU, no data-path collective
+for the maps themselves).  The patch stream is owned by rank 0 and reaches the other ranks by a
+broadcast before every replan -- the only exchange the path has (RCCL over xGMI on GPUs, gloo in
+the CPU tests).  The planner object only needs the reference surface (ReplannerBase.h:39-123)
+plus `apply_patch(buffer, top, left)`; bench.py passes the HIP planner, the CPU tests the oracle.
+"""
+import time
+
+
+class PatchStream:
+    """Rank 0 holds all patches; `fetch(i)` returns patch i on every rank."""
+
+    def __init__(self, patches, recv_buffer, dist=None, rank=0, sync=None):
+        self.patches = patches          # rank 0: sequence of patch tensors; other ranks: None / unused
+        self.recv = recv_buffer         # tensor every rank receives into
+        self.dist = dist
+        self.rank = rank
+        self.sync = sync                # callable making the broadcast result visible to the consumer
+        self.broadcasts = 0
+
+    def fetch(self, i):
+        if self.dist is None:
+            return self.patches[i]
+        if self.rank == 0:
+            self.recv.copy_(self.patches[i])
+        self.dist.broadcast(self.recv, src=0)
+        self.broadcasts += 1
+        if self.sync is not None:
+            self.sync()
+        return self.recv
+
+
+def run_episode(planner, set_map, start, goal, script, stream, apply_patch, read_stats):
+    """script: list of (k, start_xy, top, left).  Returns the summed statistics dict."""
+    tot = {}
+
+    def acc():
+        for k, v in read_stats(planner).items():
+            tot[k] = tot.get(k, 0) + v
+
+    set_map(planner)
+    planner.reset()
+    planner.set_start(*start)
+    planner.set_goal(*goal)
+    rc = planner.step()
+    if rc != 0:
+        raise RuntimeError("plan step failed: %d" % rc)
+    acc()
+    for i, (k, s, top, left) in enumerate(script):
+        apply_patch(planner, stream.fetch(i), top, left)
+        planner.set_start(*s)
+        rc = planner.step()
+        if rc != 0:
+            raise RuntimeError("replan %d failed: %d" % (k, rc))
+        acc()
+    return tot
+
+
+def timed_episodes(run_one, steps, warmup, barrier):
+    """The bench.py timing contract: W untimed warm-up steps, then exactly K steps bracketed by
+    barrier(); returns (seconds, list of per-step statistics)."""
+    for _ in range(warmup):
+        run_one()
+    barrier()
+    t0 = time.perf_counter()
+    out = [run_one() for _ in range(steps)]
+    barrier()
+    return time.perf_counter() - t0, out
