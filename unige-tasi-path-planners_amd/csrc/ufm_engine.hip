@@ -66,6 +66,8 @@ struct DevCounters {
     int qmin[2];                // k_queue_min: smallest priority queued
     float rbound;               // invalidation bound computed on the device (k_prepare_bound / k_check)
     int done;                   // k_check: both queues drained below the start's key
+    unsigned int updated;       // k_check: num_nodes_updated summed over the consuming maps
+    int pad2;
 };
 
 struct DevParams {
@@ -84,7 +86,7 @@ struct DevParams {
     int *sflag;                 // [NT] pending seeds (from patches)
     int *slist;                 // [NT]
     int *slist2;                // [NT] scratch
-    unsigned int *mark;         // [nmaps][markwords] bitmap of seeded elements
+    uint8_t *mark;              // [nmaps][EX*EY] element already counted in num_updated this round
     unsigned int *num_updated;  // [nmaps]
     int *consume;               // [nmaps]
     int *lmax;                  // [LMAX] diagnostics: per launch, the largest per-wave sweep count of any tile
@@ -96,7 +98,7 @@ struct DevParams {
     int thr;                    // Graph::occupancy_threshold_uchar_
     size_t gstride;             // floats per map in G
     size_t cstride;             // bytes per map in cost
-    size_t mstride;             // words per map in mark
+    size_t mstride;             // bytes per map in mark
 };
 
 // queue tile gt in queue qz for the launch that reads list `lst` / priority parity `par`
@@ -518,40 +520,64 @@ __global__ void k_fill(float *p, size_t n, float v) {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) p[i] = v;
 }
 
-// Graph::update (Graph.cpp:36-51) on the device + seeding of update()
-// (FD impl:127-136 corner nodes of changed cells; DFM impl:106-112 the cells).
-template <bool NODES>
-__global__ void k_patch(DevParams P, int m, const uint8_t *patch, int x, int y, int w, int h) {
+// Graph::update (Graph.cpp:36-51) on the device: overwrite the rectangle, remember which cells
+// changed (one byte per patch cell in `pmask`).
+__global__ void k_patch_apply(DevParams P, int m, const uint8_t *patch, uint8_t *pmask, int x, int y, int w, int h) {
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= w * h) return;
     const int i = e / w, j = e - i * w;
-    const int cx = x + i, cy = y + j;
     uint8_t *cm = P.cost + (size_t)m * P.cstride;
+    const size_t ci = (size_t)(x + i) * P.W + (y + j);
     const uint8_t nv = patch[e];
-    const size_t ci = (size_t)cx * P.W + cy;
-    if (cm[ci] == nv) return;
-    cm[ci] = nv;
-    const int nn = NODES ? 4 : 1;
-    for (int k = 0; k < nn; ++k) {
-        const int ex = cx + (k & 1), ey = cy + (k >> 1);   // Cell::corners, Cell.cpp:48-60
-        const size_t el = (size_t)ex * P.EY + ey;
-        const unsigned int bit = 1u << (el & 31);
-        const unsigned int old = atomicOr(&P.mark[(size_t)m * P.mstride + (el >> 5)], bit);
-        if (!(old & bit)) atomicAdd(&P.num_updated[m], 1u);
-        const int gt = m * P.NTm + (ex / T) * P.TY + (ey / T);
-        if (atomicExch(&P.sflag[gt], 1) == 0) P.slist[atomicAdd(&P.ctr->scount, 1)] = gt;
+    const uint8_t ch = cm[ci] != nv;
+    pmask[e] = ch;
+    if (ch) cm[ci] = nv;
+}
+// Seeding of update(): the corner nodes of the changed cells (FD impl:127-136, Cell.cpp:48-60) or
+// the changed cells themselves (DFM impl:106-112).  One thread per element of the patch's
+// element rectangle, so every element has one owner: plain byte marks, no atomics per element;
+// the counter and the tile seeds are aggregated per wave.
+template <bool NODES>
+__global__ void k_patch_seed(DevParams P, int m, const uint8_t *pmask, int x, int y, int w, int h) {
+    const int ew = NODES ? w + 1 : w, eh = NODES ? h + 1 : h;
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    bool hit = false;
+    int gt = -1;
+    if (e < ew * eh) {
+        const int i = e / ew, j = e - i * ew;
+        bool ch;
+        if (NODES) {   // node (x+i, y+j) touches patch cells (i-1..i, j-1..j)
+            ch = (i > 0 && j > 0 && pmask[(i - 1) * w + j - 1]) || (i > 0 && j < w && pmask[(i - 1) * w + j]) ||
+                 (i < h && j > 0 && pmask[i * w + j - 1]) || (i < h && j < w && pmask[i * w + j]);
+        } else {
+            ch = pmask[i * w + j];
+        }
+        if (ch) {
+            const int ex = x + i, ey = y + j;
+            uint8_t *mk = P.mark + (size_t)m * P.mstride + (size_t)ex * P.EY + ey;
+            hit = (*mk == 0);
+            *mk = 1;
+            gt = m * P.NTm + (ex / T) * P.TY + (ey / T);
+        }
+    }
+    const unsigned long long hm = __ballot(hit);
+    const int lane = threadIdx.x & 63;
+    if (hm && lane == 0) atomicAdd(&P.num_updated[m], (unsigned int)__popcll(hm));
+    unsigned long long todo = __ballot(gt >= 0);
+    while (todo) {                       // one seed attempt per distinct tile per wave
+        const int leader = __ffsll((long long)todo) - 1;
+        const int t = __shfl(gt, leader);
+        if (lane == leader && atomicExch(&P.sflag[t], 1) == 0) P.slist[atomicAdd(&P.ctr->scount, 1)] = t;
+        todo &= ~__ballot(gt == t);
     }
 }
 __global__ void k_clear_marks(DevParams P, int m, int x, int y, int w, int h) {
-    // zero the bitmap words covering elements (x..x+h, y..y+w)
-    const int rows = h + 1;
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
     const int r = e / (w + 1), c = e - r * (w + 1);
-    if (r >= rows) return;
+    if (r > h) return;
     const int ex = x + r, ey = y + c;
     if (ex >= P.EX || ey >= P.EY) return;
-    const size_t el = (size_t)ex * P.EY + ey;
-    P.mark[(size_t)m * P.mstride + (el >> 5)] = 0u;
+    P.mark[(size_t)m * P.mstride + (size_t)ex * P.EY + ey] = 0;
 }
 // pending seeds of consuming maps -> candidate list of launch k; others stay pending. One block.
 __global__ void k_seeds_to_active(DevParams P, int qz, int k) {
@@ -589,6 +615,17 @@ __global__ void k_queue_min(DevParams P, int qz, int k) {
     if (threadIdx.x == 0) P.ctr->qmin[qz] = s_m;
 }
 // invalidation bound for this step: the current start key plus one ordering band
+// start of a step with a single map: counters, start elements and the consume flag in one launch
+struct StepBegin { int start[4]; int consume; int clear_lmax; };
+__global__ void k_step_begin(DevParams P, StepBegin a) {
+    const int t = threadIdx.x;
+    if (t == 0) {
+        P.ctr->tcount = 0; P.ctr->expanded = 0; P.ctr->tile_visits = 0; P.ctr->tile_iters = 0; P.ctr->elem_evals = 0;
+        P.consume[0] = a.consume;
+    }
+    if (t < 4) P.start[t] = a.start[t];
+    if (a.clear_lmax) for (int i = t; i < LMAX; i += blockDim.x) P.lmax[i] = 0;
+}
 __global__ void k_prepare_bound(DevParams P, float margin) {
     if (threadIdx.x || blockIdx.x) return;
     float b = 0.0f;
@@ -618,6 +655,9 @@ __global__ void k_check(DevParams P, int kr, int kl, float margin) {
     if (again) P.ctr->rbound = fmaxf(bnew, P.ctr->rbound) + margin;
     P.ctr->qmin[Q_RAISE] = s_m;
     P.ctr->done = (raise_done && lower_done && !again) ? 1 : 0;
+    unsigned int upd = 0;
+    for (int m = 0; m < P.nmaps; ++m) if (P.consume[m]) { upd += P.num_updated[m]; P.num_updated[m] = 0; }
+    P.ctr->updated = upd;
 }
 __global__ void k_start_bound(DevParams P) {
     const int m = blockIdx.x * blockDim.x + threadIdx.x;
@@ -687,6 +727,8 @@ struct Engine {
     uint8_t *d_patch = nullptr;      // staging for host patches
     size_t d_patch_cap = 0;
     uint8_t *h_patch = nullptr;      // pinned staging
+    uint8_t *d_pmask = nullptr;      // changed-cell mask of the patch being applied
+    size_t d_pmask_cap = 0;
     std::vector<MapState> maps;
     std::vector<PatchRect> pending;
     std::vector<uint64_t> upd_pending;   // per map
@@ -738,7 +780,7 @@ int Engine::alloc(int width, int length) {
     P.pitch = P.TY * T + 2 * GPAD;
     P.gstride = (size_t)(P.TX * T + 2) * P.pitch;
     P.cstride = (size_t)L * W;
-    P.mstride = ((size_t)P.EX * P.EY + 31) / 32 + 1;
+    P.mstride = (size_t)P.EX * P.EY;
     P.thr = thr_uchar;
     const size_t gbytes = P.gstride * nmaps * sizeof(float);
     HIPCHK(hipMalloc(&P.G, gbytes));
@@ -756,7 +798,7 @@ int Engine::alloc(int width, int length) {
     HIPCHK(hipMalloc(&P.sflag, sizeof(int) * P.NT));
     HIPCHK(hipMalloc(&P.slist, sizeof(int) * P.NT));
     HIPCHK(hipMalloc(&P.slist2, sizeof(int) * P.NT));
-    HIPCHK(hipMalloc(&P.mark, sizeof(unsigned int) * P.mstride * nmaps));
+    HIPCHK(hipMalloc(&P.mark, P.mstride * nmaps));
     HIPCHK(hipMalloc(&P.num_updated, sizeof(unsigned int) * nmaps));
     HIPCHK(hipMalloc(&P.consume, sizeof(int) * nmaps));
     HIPCHK(hipMalloc(&P.lmax, sizeof(int) * LMAX));
@@ -767,7 +809,7 @@ int Engine::alloc(int width, int length) {
     { int rc = reset_queues(); if (rc != UFM_OK) return rc; }
     HIPCHK(hipMemsetAsync(P.touched, 0, sizeof(int) * P.NT, stream));
     HIPCHK(hipMemsetAsync(P.sflag, 0, sizeof(int) * P.NT, stream));
-    HIPCHK(hipMemsetAsync(P.mark, 0, sizeof(unsigned int) * P.mstride * nmaps, stream));
+    HIPCHK(hipMemsetAsync(P.mark, 0, P.mstride * nmaps, stream));
     HIPCHK(hipMemsetAsync(P.num_updated, 0, sizeof(unsigned int) * nmaps, stream));
     HIPCHK(hipMemsetAsync(P.goal, 0xFF, sizeof(int) * 2 * nmaps, stream));
     k_fill<<<1024, 256, 0, stream>>>(P.G, P.gstride * nmaps, INFINITY);
@@ -864,8 +906,15 @@ int Engine::patch(int m, const uint8_t *dev_patch, int x, int y, int w, int h) {
     if (m < 0 || m >= nmaps || !allocated || !maps[m].have_map) return UFM_ERR_INVALID;
     if (x < 0 || y < 0 || w <= 0 || h <= 0 || x + h > L || y + w > W) return UFM_ERR_INVALID;   // Graph.cpp:38-41
     const int n = w * h;
-    if (algo == UFM_ALGO_DFM) k_patch<false><<<(n + 255) / 256, 256, 0, stream>>>(P, m, dev_patch, x, y, w, h);
-    else k_patch<true><<<(n + 255) / 256, 256, 0, stream>>>(P, m, dev_patch, x, y, w, h);
+    if ((size_t)n > d_pmask_cap) {
+        if (d_pmask) { HIPCHK(hipStreamSynchronize(stream)); hipFree(d_pmask); }
+        d_pmask_cap = n < 4096 ? 4096 : (size_t)n;
+        HIPCHK(hipMalloc(&d_pmask, d_pmask_cap));
+    }
+    k_patch_apply<<<(n + 255) / 256, 256, 0, stream>>>(P, m, dev_patch, d_pmask, x, y, w, h);
+    const int ne = (w + 1) * (h + 1);
+    if (algo == UFM_ALGO_DFM) k_patch_seed<false><<<(ne + 255) / 256, 256, 0, stream>>>(P, m, d_pmask, x, y, w, h);
+    else k_patch_seed<true><<<(ne + 255) / 256, 256, 0, stream>>>(P, m, d_pmask, x, y, w, h);
     HIPCHK(hipGetLastError());
     pending.push_back({m, x, y, w, h});
     return UFM_OK;
@@ -878,9 +927,12 @@ int Engine::step(ufm_stats *out) {
     ufm_stats st{};
     const auto t0 = std::chrono::steady_clock::now();
 
-    HIPCHK(hipMemsetAsync(&P.ctr->tcount, 0, sizeof(int), stream));
-    HIPCHK(hipMemsetAsync(&P.ctr->expanded, 0, 4 * sizeof(unsigned long long), stream));
-    if (profiling) HIPCHK(hipMemsetAsync(P.lmax, 0, sizeof(int) * LMAX, stream));
+    const bool single = (nmaps == 1);
+    if (!single) {
+        HIPCHK(hipMemsetAsync(&P.ctr->tcount, 0, sizeof(int), stream));
+        HIPCHK(hipMemsetAsync(&P.ctr->expanded, 0, 4 * sizeof(unsigned long long), stream));
+        if (profiling) HIPCHK(hipMemsetAsync(P.lmax, 0, sizeof(int) * LMAX, stream));
+    }
     P.focused = focused ? 1 : 0;
 
     // classify maps: (re)initialise, propagate pending patches, or idle  (ReplannerBase.h:48-59)
@@ -926,14 +978,22 @@ int Engine::step(ufm_stats *out) {
                 if (ex >= 0 && ey >= 0 && ex < P.EX && ey < P.EY) st_el[4 * m + i] = ex * P.EY + ey;
             }
         }
-        HIPCHK(hipMemcpyAsync(P.start, st_el, sizeof(int) * 4 * nmaps, hipMemcpyHostToDevice, stream));
+        if (single) {
+            StepBegin sb;
+            for (int i = 0; i < 4; ++i) sb.start[i] = st_el[i];
+            sb.consume = consume[0];
+            sb.clear_lmax = profiling ? 1 : 0;
+            k_step_begin<<<1, 256, 0, stream>>>(P, sb);
+        } else {
+            HIPCHK(hipMemcpyAsync(P.start, st_el, sizeof(int) * 4 * nmaps, hipMemcpyHostToDevice, stream));
+        }
     }
     uint64_t updated = 0;
     bool have_seeds = false;
     bool fast_done = false;
     const float band = (delta_abs >= 0.0f ? delta_abs : delta_scale * T * mean_cost);
     if (n_upd > 0 || n_init > 0) {
-        HIPCHK(hipMemcpyAsync(P.consume, consume, sizeof(int) * nmaps, hipMemcpyHostToDevice, stream));
+        if (!single) HIPCHK(hipMemcpyAsync(P.consume, consume, sizeof(int) * nmaps, hipMemcpyHostToDevice, stream));
         // consume pending patch rectangles of the participating maps
         std::vector<PatchRect> keep;
         for (const PatchRect &r : pending) {
@@ -967,13 +1027,10 @@ int Engine::step(ufm_stats *out) {
         k_check<<<1, 1024, 0, stream>>>(P, iter[Q_RAISE], iter[Q_LOWER], band);
         k_finalize<<<grid_relax, NTHR, 0, stream>>>(P, 1);
         HIPCHK(hipMemcpyAsync(h_ctr, P.ctr, sizeof(DevCounters), hipMemcpyDeviceToHost, stream));
-        HIPCHK(hipMemcpyAsync(h_scratch + 4 * nmaps, P.num_updated, sizeof(unsigned int) * nmaps, hipMemcpyDeviceToHost, stream));
-        HIPCHK(hipMemsetAsync(P.num_updated, 0, sizeof(unsigned int) * nmaps, stream));
         HIPCHK(hipGetLastError());
         HIPCHK(hipStreamSynchronize(stream));
         if (profiling) { float ms = 0; HIPCHK(hipEventElapsedTime(&ms, e0, e1)); st.kernel_ms += ms; }
-        const unsigned int *nu = reinterpret_cast<const unsigned int *>(h_scratch + 4 * nmaps);
-        for (int m = 0; m < nmaps; ++m) if (consume[m]) updated += nu[m];
+        updated += h_ctr->updated;
         st.raise_launches += (uint32_t)nr;
         st.launches += (uint32_t)(nr + nl);
         fast_done = h_ctr->done != 0;
@@ -1124,6 +1181,7 @@ int engine_destroy(Engine *e) {
     e->release();
     for (hipEvent_t v : e->ev) hipEventDestroy(v);
     if (e->d_patch) hipFree(e->d_patch);
+    if (e->d_pmask) hipFree(e->d_pmask);
     if (e->h_patch) hipHostFree(e->h_patch);
     if (e->h_ctr) hipHostFree(e->h_ctr);
     if (e->h_scratch) hipHostFree(e->h_scratch);
