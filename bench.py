@@ -111,7 +111,10 @@ def main():
             start=start, goal=goal, script=meta, stream=stream,
             apply_patch=lambda p, buf, top, left: p.patch_map_device(buf.data_ptr(), top, left, psz, psz),
             read_stats=lambda p: {"cells": p.stats.expanded, "visits": p.stats.tile_visits, "launches": p.stats.launches,
-                                  "kernel_ms": p.stats.kernel_ms, "evals": p.stats.elem_evals})
+                                  "kernel_ms": p.stats.kernel_ms, "evals": p.stats.elem_evals,
+                                  "lower_visits": p.stats.tile_visits - p.stats.raise_tile_visits,
+                                  "lower_launches": p.stats.launches - p.stats.raise_launches,
+                                  "lower_kernel_ms": p.stats.kernel_ms - p.stats.raise_kernel_ms})
 
     def barrier():
         torch.cuda.synchronize()
@@ -121,6 +124,7 @@ def main():
 
     dt, per_step = ep.timed_episodes(run_one, args.steps, args.warmup, barrier)
     tot = [sum(d[k] for d in per_step) for k in ("cells", "visits", "launches", "kernel_ms", "evals")]
+    low = [sum(d[k] for d in per_step) for k in ("lower_visits", "lower_launches", "lower_kernel_ms")]
 
     cells, visits, launches, kms, evals = tot
     if dist is not None:
@@ -156,14 +160,23 @@ def main():
                 "elem_evals_per_step_rank0": evals / max(1, args.steps),
             },
         }
-        if kms > 0 and launches > 0:
-            achieved = visits * BYTES_PER_TILE_VISIT / (kms * 1e-3) / 1e9
+        lvis, llaunch, lkms = low
+        if lkms > 0 and llaunch > 0:
+            # dominant kernel: k_relax<algo, LOWER>.  Algorithmic bytes = tile visits x (9 B per element
+            # + halo) per SURVEY.md 8(d); duration = HIP events on the engine's stream around its launches.
+            achieved = lvis * BYTES_PER_TILE_VISIT / (lkms * 1e-3) / 1e9
+            traffic = None
+            tj = os.path.join(ROOT, "profiles", "r1_traffic.json")
+            if os.path.exists(tj) and args.algo == "FD" and size == 4096:
+                traffic = json.load(open(tj)).get("traffic_bytes_per_launch")   # rocprofv3 PMC, same command
             out["roofline"] = {
-                "bound": "hbm", "kernel": "k_relax", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                "avg_launch_us": 1e3 * kms / launches,
-                "algorithmic_bytes_per_launch": visits * BYTES_PER_TILE_VISIT / launches,
+                "bound": "hbm", "kernel": "k_relax<%s,LOWER>" % args.algo, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                "avg_launch_us": 1e3 * lkms / llaunch,
+                "algorithmic_bytes_per_launch": lvis * BYTES_PER_TILE_VISIT / llaunch,
+                "tile_visits_per_launch": lvis / llaunch,
                 "kernel_time_share": kms * 1e-3 / dt,
+                "note": "latency-bound (dependent in-LDS sweeps along the wavefront), not bandwidth-bound: see DESIGN.md",
             }
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.cpu_size, seed, args.patches)

@@ -53,6 +53,8 @@ typedef struct ufm_stats {
     uint32_t raise_launches;   /* of which in the invalidation phase */
     float kernel_ms;           /* summed relax-kernel time (HIP events) if profiling is on, else 0 */
     uint64_t crit_sweeps;      /* profiling only: sum over launches of the slowest tile's sweep count */
+    uint64_t raise_tile_visits; /* tile visits of the invalidation kernel (subset of tile_visits) */
+    float raise_kernel_ms;     /* part of kernel_ms spent in the invalidation kernel */
 } ufm_stats;
 
 /* ---- lifetime: `PlannerT<OPT_LVL> planner{}` (e.g. Tests/Planners/FDSTAR/main.cpp:77) ---- */

@@ -136,3 +136,98 @@ def test_focused_and_full_field_agree_below_the_start_key(algo):
     assert work[0] < work[1]          # focusing must save work
     for p in ps:
         p.close()
+
+
+def test_result_independent_of_scheduler_knobs():
+    """Band width, sweep cap and grid size are scheduling knobs only (full-field mode: bitwise)."""
+    width, length = 224, 160
+    cost = ufm_amd.synth.cost_map(4, width, length)
+    start, goal = ufm_amd.synth.start_goal(width, length)
+    fields = []
+    for scale, cap, grid in [(1.0, 128, 512), (0.25, 128, 512), (1e9, 128, 64), (2.0, 3, 7)]:
+        p = ufm_amd.Planner(ufm_amd.ALGO_SG, 0)
+        p.set_param("focused", 0); p.set_param("delta_scale", scale); p.set_param("max_iters", cap); p.set_param("grid", grid)
+        p.set_occupancy_threshold(1); p.set_map(cost); p.set_start(*start); p.set_goal(*goal)
+        assert p.step() == 0
+        for k, s, top, left, patch in ufm_amd.synth.replan_script(4, width, length, n_patches=5):
+            p.patch_map(patch, top, left); p.set_start(*s)
+            assert p.step() == 0
+        fields.append(p.g())
+        p.close()
+    for f in fields[1:]:
+        assert np.array_equal(fields[0], f)
+
+
+def test_edge_cases():
+    # tiny maps, maps smaller than a tile, non-multiple-of-tile sizes, goal in a corner, start == goal
+    for (w, l) in [(1, 1), (3, 2), (33, 31), (64, 65)]:
+        cost = np.full((l, w), 7, dtype=np.uint8)
+        for algo in ("FD", "SG", "DFM"):
+            o, g = make_pair(ALGOS[algo], 0, cost, (0.0, 0.0), (float(l - 1), float(w - 1)))
+            assert o.step() == 0 and g.step() == 0
+            check_parity(o, g, "%s %dx%d" % (algo, w, l))
+            g.close()
+    # a wall that separates start and goal: everything behind it stays +inf on both sides
+    cost = np.full((40, 40), 5, dtype=np.uint8)
+    cost[:, 20] = 255
+    o, g = make_pair(ALGOS["FD"], 0, cost, (5.0, 5.0), (30.0, 30.0))
+    assert o.step() == 0 and g.step() == 0
+    gg = g.g()
+    assert np.isinf(gg[:, :20]).all() and np.isfinite(gg[:, 22:]).all()
+    # return codes of step() without a map / without a goal (ReplannerBase.h:44-45)
+    p = ufm_amd.Planner(ufm_amd.ALGO_FD, 0)
+    assert p.step() == ufm_amd.LOOP_FAILURE_NO_GRAPH
+    p.set_map(cost)
+    assert p.step() == ufm_amd.LOOP_FAILURE_NO_GOAL
+    p.close(); g.close()
+
+
+def test_occupancy_threshold_semantics():
+    # Graph.cpp:18-20,267: byte >= int(thr*255) is an obstacle; default 254
+    cost = np.full((48, 48), 10, dtype=np.uint8)
+    cost[10:20, 10:20] = 254
+    for thr in (None, 1.0, 0.5):
+        o = __import__("oracle_py").OraclePlanner(0, 0, False)
+        g = ufm_amd.Planner(0, 0)
+        for p in (o, g):
+            p.reset()
+            if thr is not None:
+                p.set_occupancy_threshold(thr)
+            p.set_map(cost); p.set_start(2.0, 2.0); p.set_goal(40.0, 40.0)
+            assert p.step() == 0
+        n, nbad = check_parity(o, g, "thr %s" % thr)
+        assert nbad == 0
+        g.close()
+
+
+def test_batch_of_independent_maps():
+    n, size = 5, 128
+    b = ufm_amd.BatchPlanner(n, ufm_amd.ALGO_DFM, 0)
+    b.set_occupancy_threshold(1)
+    import oracle_py as orc
+    oracles = []
+    for i in range(n):
+        cost = ufm_amd.synth.cost_map(1000 + i, size, size)
+        start, goal = ufm_amd.synth.start_goal(size, size)
+        b.set_map(i, cost); b.set_start(i, *start); b.set_goal(i, *goal)
+        o = orc.OraclePlanner(orc.ALGO_DFM, 0, False)
+        o.reset(); o.set_occupancy_threshold(1); o.set_map(cost); o.set_start(*start); o.set_goal(*goal)
+        assert o.step() == 0
+        oracles.append(o)
+    assert b.step() == 0
+    for i, o in enumerate(oracles):
+        m = o.trusted_mask()
+        a, ref = b.read_field(i)[m], o.g()[m]
+        assert np.all(np.abs(a.astype(np.float64) - ref) <= 1e-6 * ref)
+    # patch two of the maps, leave the others alone
+    for i in (1, 3):
+        patch = np.full((9, 9), 3 + i, dtype=np.uint8)
+        b.patch_map(i, patch, 60, 60); b.set_start(i, 8.0, 8.0)
+        oracles[i].patch_map(patch, 60, 60); oracles[i].set_start(8.0, 8.0)
+        assert oracles[i].step() == 0
+    assert b.step() == 0
+    for i, o in enumerate(oracles):
+        m = o.trusted_mask()
+        a, ref = b.read_field(i)[m], o.g()[m]
+        assert np.all(np.abs(a.astype(np.float64) - ref) <= 1e-6 * ref), i
+    b.close()

@@ -5,7 +5,9 @@ calls = collections.Counter()
 seen = set()
 with open(sys.argv[1]) as f:
     for row in csv.DictReader(f):
-        k = row["Kernel_Name"].split("(")[0][-40:]
+        k = row["Kernel_Name"]
+        k = k.replace("(anonymous namespace)::", "").replace("void ", "")
+        k = k.split("(")[0][:60]
         acc[k][row["Counter_Name"]] += float(row["Counter_Value"])
         key = (row["Dispatch_Id"])
         if key not in seen:

@@ -36,6 +36,8 @@ class Stats(C.Structure):
         ("launches", C.c_uint32), ("raise_launches", C.c_uint32),
         ("kernel_ms", C.c_float),
         ("crit_sweeps", C.c_uint64),
+        ("raise_tile_visits", C.c_uint64),
+        ("raise_kernel_ms", C.c_float),
     ]
 
     def as_dict(self):

@@ -68,6 +68,7 @@ struct DevCounters {
     int done;                   // k_check: both queues drained below the start's key
     unsigned int updated;       // k_check: num_nodes_updated summed over the consuming maps
     int pad2;
+    unsigned long long raise_visits;   // tile visits of the invalidation kernel (subset of tile_visits)
 };
 
 struct DevParams {
@@ -505,6 +506,7 @@ __global__ __launch_bounds__(NTHR) void k_relax(DevParams P, int k, float delta,
                 if (!conv) activate(P, Q, rn, pn, gt, min(s_bmin[4], INFBITS - 1));   // sweep cap hit: come back
                 atomicMax(&P.lmax[k & (LMAX - 1)], s_misc[3]);
                 atomicAdd(&P.ctr->tile_visits, 1ull);
+                if (MODE == MODE_RAISE) atomicAdd(&P.ctr->raise_visits, 1ull);
                 atomicAdd(&P.ctr->tile_iters, (unsigned long long)s_misc[3]);
                 atomicAdd(&P.ctr->elem_evals, 16ull * (unsigned long long)s_misc[2]);
             } else if (s_bmin[tid] != INFBITS) {
@@ -621,6 +623,7 @@ __global__ void k_step_begin(DevParams P, StepBegin a) {
     const int t = threadIdx.x;
     if (t == 0) {
         P.ctr->tcount = 0; P.ctr->expanded = 0; P.ctr->tile_visits = 0; P.ctr->tile_iters = 0; P.ctr->elem_evals = 0;
+        P.ctr->raise_visits = 0;
         P.consume[0] = a.consume;
     }
     if (t < 4) P.start[t] = a.start[t];
@@ -931,6 +934,7 @@ int Engine::step(ufm_stats *out) {
     if (!single) {
         HIPCHK(hipMemsetAsync(&P.ctr->tcount, 0, sizeof(int), stream));
         HIPCHK(hipMemsetAsync(&P.ctr->expanded, 0, 4 * sizeof(unsigned long long), stream));
+        HIPCHK(hipMemsetAsync(&P.ctr->raise_visits, 0, sizeof(unsigned long long), stream));
         if (profiling) HIPCHK(hipMemsetAsync(P.lmax, 0, sizeof(int) * LMAX, stream));
     }
     P.focused = focused ? 1 : 0;
@@ -1014,22 +1018,28 @@ int Engine::step(ufm_stats *out) {
         k_seeds_to_active<<<1, 1024, 0, stream>>>(P, Q_RAISE, iter[Q_RAISE]);
         k_prepare_bound<<<1, 64, 0, stream>>>(P, band);
         const int nr = hist_raise + 2, nl = hist_lower + 2;
-        hipEvent_t e0 = nullptr, e1 = nullptr;
+        hipEvent_t e0 = nullptr, e1 = nullptr, e2 = nullptr, e3 = nullptr;
         if (profiling) {
-            while (ev.size() < 2) { hipEvent_t a; HIPCHK(hipEventCreate(&a)); ev.push_back(a); }
-            e0 = ev[0]; e1 = ev[1];
+            while (ev.size() < 4) { hipEvent_t a; HIPCHK(hipEventCreate(&a)); ev.push_back(a); }
+            e0 = ev[0]; e1 = ev[1]; e2 = ev[2]; e3 = ev[3];
             HIPCHK(hipEventRecord(e0, stream));
         }
         for (int i = 0; i < nr; ++i) launch_relax(MODE_RAISE, -1.0f);
-        k_touched_to_active<<<64, 256, 0, stream>>>(P, Q_LOWER, iter[Q_LOWER]);
-        for (int i = 0; i < nl; ++i) launch_relax(MODE_LOWER, INFINITY);
         if (profiling) HIPCHK(hipEventRecord(e1, stream));
+        k_touched_to_active<<<64, 256, 0, stream>>>(P, Q_LOWER, iter[Q_LOWER]);
+        if (profiling) HIPCHK(hipEventRecord(e2, stream));
+        for (int i = 0; i < nl; ++i) launch_relax(MODE_LOWER, INFINITY);
+        if (profiling) HIPCHK(hipEventRecord(e3, stream));
         k_check<<<1, 1024, 0, stream>>>(P, iter[Q_RAISE], iter[Q_LOWER], band);
         k_finalize<<<grid_relax, NTHR, 0, stream>>>(P, 1);
         HIPCHK(hipMemcpyAsync(h_ctr, P.ctr, sizeof(DevCounters), hipMemcpyDeviceToHost, stream));
         HIPCHK(hipGetLastError());
         HIPCHK(hipStreamSynchronize(stream));
-        if (profiling) { float ms = 0; HIPCHK(hipEventElapsedTime(&ms, e0, e1)); st.kernel_ms += ms; }
+        if (profiling) {
+            float ms = 0;
+            HIPCHK(hipEventElapsedTime(&ms, e0, e1)); st.kernel_ms += ms; st.raise_kernel_ms += ms;
+            HIPCHK(hipEventElapsedTime(&ms, e2, e3)); st.kernel_ms += ms;
+        }
         updated += h_ctr->updated;
         st.raise_launches += (uint32_t)nr;
         st.launches += (uint32_t)(nr + nl);
@@ -1089,8 +1099,10 @@ int Engine::step(ufm_stats *out) {
             const auto ta = std::chrono::steady_clock::now();
             if (do_raise) {
                 uint32_t rl = 0;
-                int rc = run_phase(MODE_RAISE, rbound, &rl, &st.kernel_ms);
+                float rk = 0.0f;
+                int rc = run_phase(MODE_RAISE, rbound, &rl, &rk);
                 if (rc != UFM_OK) return rc;
+                st.kernel_ms += rk; st.raise_kernel_ms += rk;
                 st.raise_launches += rl;
                 st.launches += rl;
                 // everything invalidation touched must be re-lowered
@@ -1126,6 +1138,7 @@ int Engine::step(ufm_stats *out) {
         st.tile_visits = h_ctr->tile_visits;
         st.tile_iters = h_ctr->tile_iters;
         st.elem_evals = h_ctr->elem_evals;
+        st.raise_tile_visits = h_ctr->raise_visits;
         if (profiling) {   // diagnostics: sum over launches of the slowest tile's sweep count
             std::vector<int> lm(LMAX);
             HIPCHK(hipMemcpy(lm.data(), P.lmax, sizeof(int) * LMAX, hipMemcpyDeviceToHost));
@@ -1137,6 +1150,7 @@ int Engine::step(ufm_stats *out) {
         st.tile_visits = h_ctr->tile_visits;
         st.tile_iters = h_ctr->tile_iters;
         st.elem_evals = h_ctr->elem_evals;
+        st.raise_tile_visits = h_ctr->raise_visits;
         const double dt = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_seed).count();
         u_acc += 0.5 * dt;   // invalidation and lowering ran in one submission: split evenly
         p_acc += 0.5 * dt;
