@@ -95,8 +95,8 @@ int ufm_read_map(ufm_t *p, uint8_t *host_map);
 
 /* ---- tuning knobs of the tile scheduler (no reference counterpart; results do not depend
  * on them).  "delta": absolute width of the ordering band in cost units (< 0: automatic);
- * "delta_scale": band = scale * tile edge * mean traversable cost (default 1);
- * "max_iters": in-LDS sweep cap per tile visit; "batch": relax launches per host check
+ * "delta_scale": band = scale * tile edge * mean traversable cost (default 1.5);
+ * "max_iters": in-LDS sweep cap per tile visit (default 32); "batch": relax launches per host check
  * (0: adaptive); "grid": workgroups per relax launch.
  * "focused" (default 1): honour the reference's end_condition -- propagate only as far as the
  * start's key and keep the rest queued for later steps, like the reference's priority queue;

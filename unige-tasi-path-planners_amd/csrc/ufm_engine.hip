@@ -740,9 +740,10 @@ struct Engine {
     float *h_bnd = nullptr;          // pinned [nmaps]
     int hist_raise = 3, hist_lower = 4;   // blind batch sizes of the replan fast path
     int grid_relax = 512;
-    int max_iters = 4 * T;
+    int max_iters = 32;              // sweep cap per tile visit (x4 patch sweeps per wave): a tile that needs more is
+                                     // re-queued instead of holding the whole launch (measured optimum on 4096^2)
     float delta_abs = -1.0f;         // ordering band; < 0: delta_scale * T * mean traversable cost
-    float delta_scale = 1.0f;
+    float delta_scale = 1.5f;
     float mean_cost = 1.0f;
     int batch_fixed = 0;
     bool profiling = false;
