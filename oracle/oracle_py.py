@@ -4,6 +4,7 @@ TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and the
 cpu_baseline leg of bench.py.  The product path never imports this module.
 """
 import ctypes as C
+import math
 import os
 import subprocess
 
@@ -54,6 +55,11 @@ def lib():
     return _LIB
 
 
+def _roundf(v):
+    """C roundf: half away from zero (Node(Position) / Cell(Position), Node.cpp:14-17)"""
+    return int(math.copysign(math.floor(abs(v) + 0.5), v))
+
+
 class OraclePlanner:
     """Mirror of the reference planner surface (ReplannerBase.h:39-123)."""
 
@@ -63,6 +69,9 @@ class OraclePlanner:
         if not self.h:
             raise ValueError("bad algo/opt_lvl")
         self.algo, self.opt_lvl = algo, opt_lvl
+        self.use_heuristic = bool(use_heuristic)
+        self.hm = 1.0
+        self.start = None
 
     def __del__(self):
         if getattr(self, "h", None):
@@ -76,6 +85,7 @@ class OraclePlanner:
         self.L.orc_set_occupancy_threshold(self.h, float(t))
 
     def set_heuristic_multiplier(self, m):
+        self.hm = float(m)
         self.L.orc_set_heuristic_multiplier(self.h, float(m))
 
     def set_map(self, m):
@@ -89,6 +99,7 @@ class OraclePlanner:
         self.L.orc_patch_map(self.h, patch.ctypes.data, int(x), int(y), w, h)
 
     def set_start(self, x, y):
+        self.start = (float(x), float(y))
         self.L.orc_set_start(self.h, float(x), float(y))
 
     def set_goal(self, x, y):
@@ -151,10 +162,37 @@ class OraclePlanner:
         self.L.orc_top_key(self.h, C.byref(a), C.byref(b))
         return a.value, b.value
 
-    def trusted_mask(self):
-        """Elements whose value the reference guarantees final after step():
-        locally consistent (G==RHS<inf) and, D*-Lite invariant, with
-        G <= key at the top of the queue (NO_HEURISTIC keys)."""
+    def key1(self):
+        """first key component of every element for its current G: G (+ hm * dist(start, s))"""
+        g = self.g()
+        if not self.use_heuristic or self.start is None:
+            return g
+        nx, ny = g.shape
+        sx, sy = self.start
+        if self.algo == ALGO_DFM:
+            sx, sy = float(_roundf(sx)), float(_roundf(sy))
+        xi, yi = np.meshgrid(np.arange(nx, dtype=np.float32), np.arange(ny, dtype=np.float32), indexing="ij")
+        return (g + np.float32(self.hm) * np.hypot(np.float32(sx) - xi, np.float32(sy) - yi).astype(np.float32)).astype(np.float32)
+
+    def start_key(self):
+        """the reference's max_start_key (first component): over the start elements that are reached"""
+        g, k1 = self.g(), self.key1()
+        if self.start is None:
+            return np.inf
+        cx, cy = _roundf(self.start[0]), _roundf(self.start[1])
+        elems = [(cx, cy)] if self.algo == ALGO_DFM else [(cx, cy), (cx + 1, cy), (cx, cy + 1), (cx + 1, cy + 1)]
+        ks = [k1[x, y] for x, y in elems if 0 <= x < g.shape[0] and 0 <= y < g.shape[1] and np.isfinite(self.rhs()[x, y])]
+        return max(ks) if ks else np.inf
+
+    def trusted_mask(self, below_start_key=False):
+        """Elements whose value the reference guarantees final after step(): locally consistent
+        (G==RHS<inf) and, D*-Lite invariant, with key not beyond the top of the queue.
+        below_start_key additionally restricts to keys below the start's key -- the set a
+        planner that honours end_condition must have finalised."""
         g, rhs = self.g(), self.rhs()
-        k1, _ = self.top_key()
-        return (g == rhs) & np.isfinite(g) & (g <= k1)
+        k1t, k2t = self.top_key()
+        k1 = self.key1()
+        m = (g == rhs) & np.isfinite(g) & ((k1 < k1t) | ((k1 == k1t) & (g <= k2t if self.use_heuristic else True)))
+        if below_start_key:
+            m &= k1 < self.start_key()
+        return m

@@ -7,15 +7,15 @@ import ufm_amd
 ALGOS = {"FD": 0, "SG": 1, "DFM": 2}
 
 
-def make_pair(algo, opt_lvl, cost, start, goal, thr=1.0):
+def make_pair(algo, opt_lvl, cost, start, goal, thr=1.0, heuristic=False, hm=1.0):
     """Configure an oracle planner and a HIP planner the way the reference's
     demo drivers do (Tests/Planners/FDSTAR/main.cpp:82-88)."""
-    o = orc.OraclePlanner(algo, opt_lvl, False)
-    g = ufm_amd.Planner(algo, opt_lvl, False)
+    o = orc.OraclePlanner(algo, opt_lvl, heuristic)
+    g = ufm_amd.Planner(algo, opt_lvl, heuristic)
     for p in (o, g):
         p.reset()
         p.set_occupancy_threshold(thr)
-        p.set_heuristic_multiplier(1)
+        p.set_heuristic_multiplier(hm)
         p.set_map(cost)
         p.set_start(*start)
         p.set_goal(*goal)
@@ -29,12 +29,12 @@ def ulp_diff(a, b):
     return np.abs(ia - ib)
 
 
-def check_parity(o, g, what=""):
+def check_parity(o, g, what="", below_start_key=False):
     """Compare the HIP field with the oracle on the set of elements whose value
     the reference guarantees final (consistent and not beyond the queue top).
     Target: bit-equal.  Acceptance bound: |dG| <= max(1e-6*G, 2 ulp)."""
     og, orhs = o.g(), o.rhs()
-    mask = o.trusted_mask()
+    mask = o.trusted_mask(below_start_key=below_start_key)
     gg, grhs = g.read_field()
     assert gg.shape == og.shape, (gg.shape, og.shape)
     n = int(mask.sum())

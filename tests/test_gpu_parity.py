@@ -231,3 +231,39 @@ def test_batch_of_independent_maps():
         a, ref = b.read_field(i)[m], o.g()[m]
         assert np.all(np.abs(a.astype(np.float64) - ref) <= 1e-6 * ref), i
     b.close()
+
+
+@pytest.mark.parametrize("algo,lvl", [("FD", 1), ("SG", 2), ("DFM", 1)])
+def test_heuristic_keys(algo, lvl):
+    """Planners built with heuristic keys (the reference's default, no -DNO_HEURISTIC): the engine
+    prunes tiles whose admissible key bound is not below the start's key.  Everything the reference
+    guarantees final AND a planner honouring end_condition must have finalised (key < start key)
+    has to match; the heuristic multiplier is the map's minimum cost as in the reference harness."""
+    width = length = 224
+    seed = 31
+    cost = ufm_amd.synth.cost_map(seed, width, length)
+    hm = float(cost.min())
+    # start in the interior so that the heuristic actually prunes part of the map
+    start, goal = (60.0, 70.0), (float(length - 8), float(width - 8))
+    o, g = make_pair(ALGOS[algo], lvl, cost, start, goal, heuristic=True, hm=hm)
+    assert o.step() == 0 and g.step() == 0
+    n, nbad = check_parity(o, g, "%s heuristic first plan" % algo, below_start_key=True)
+    assert n > 1000
+    if algo != "DFM":
+        assert nbad == 0
+    reached = np.isfinite(g.g()).sum()
+    assert reached < 0.98 * g.g().size        # the search was focused: part of the map never got relaxed
+    sx, sy = start
+    for k in range(1, 13):
+        top, left = int(sx) - 15 + 3 * k, int(sy) - 15 + 2 * k
+        patch = (1 + (ufm_amd.synth.h64(seed ^ k, *np.meshgrid(np.arange(top, top + 31), np.arange(left, left + 31), indexing="ij")) % np.uint64(200))).astype(np.uint8)
+        s = (sx + 3 * k, sy + 2 * k)
+        for p in (o, g):
+            p.patch_map(patch, top, left)
+            p.set_heuristic_multiplier(hm)
+            p.set_start(*s)
+        assert o.step() == 0 and g.step() == 0
+        n, nbad = check_parity(o, g, "%s heuristic replan %d" % (algo, k), below_start_key=True)
+        if algo != "DFM":
+            assert nbad == 0, (k, nbad, n)
+    g.close()

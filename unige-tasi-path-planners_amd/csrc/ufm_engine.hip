@@ -82,6 +82,8 @@ struct DevParams {
     int *start;                 // [nmaps][4] start elements (linear index in the map, -1 unused)
     float *bnd;                 // [nmaps] k_start_bound output
     int focused;                // honour the reference's end condition (stop at the start's key)
+    float hm;                   // heuristic multiplier of the keys (0 when built like -DNO_HEURISTIC)
+    float *spos;                // [nmaps][2] start position (FD/SG: Position; DFM: start cell indices)
     int *touched;               // [NT]
     int *tlist;                 // [NT]
     int *sflag;                 // [NT] pending seeds (from patches)
@@ -116,14 +118,25 @@ __device__ __forceinline__ void activate(const DevParams &P, int qz, int lst, in
 __device__ __forceinline__ float start_bound(const DevParams &P, int m) {
     float b = 0.0f;
     const float *Gm = P.G + (size_t)m * P.gstride;
+    const float sx = P.spos[2 * m], sy = P.spos[2 * m + 1];
     for (int i = 0; i < 4; ++i) {
         const int e = P.start[4 * m + i];
         if (e < 0) continue;
         const int x = e / P.EY, y = e - x * P.EY;
         const float g = __hip_atomic_load(&Gm[(size_t)(x + 1) * P.pitch + (y + GPAD)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (g < INFINITY) b = fmaxf(b, g);
+        // heuristic keys (FD impl:178-186, DFM impl:146-155): first component k + hm * dist(start, s)
+        if (g < INFINITY) b = fmaxf(b, g + P.hm * hypotf(sx - (float)x, sy - (float)y));
     }
     return b > 0.0f ? b : INFINITY;
+}
+// admissible lower bound of hm * dist(start, s) over the elements s of a tile: with heuristic keys
+// an element is only worth relaxing while value + hm * dist < the start's key
+__device__ __forceinline__ float tile_heuristic(const DevParams &P, int m, int tx, int ty) {
+    if (P.hm == 0.0f) return 0.0f;
+    const float sx = P.spos[2 * m], sy = P.spos[2 * m + 1];
+    const float x0 = (float)(tx * T), x1 = (float)(tx * T + T - 1), y0 = (float)(ty * T), y1 = (float)(ty * T + T - 1);
+    const float dx = fmaxf(fmaxf(x0 - sx, sx - x1), 0.0f), dy = fmaxf(fmaxf(y0 - sy, sy - y1), 0.0f);
+    return P.hm * hypotf(dx, dy) * 0.999f;   // (0.999: stay below the reference's own float rounding of the distance)
 }
 
 // ---- update operators -------------------------------------------------------
@@ -340,7 +353,8 @@ __global__ __launch_bounds__(NTHR) void k_relax(DevParams P, int k, float delta,
         bool release;
         if (MODE == MODE_LOWER) {
             const float B = P.focused ? start_bound(P, m) : INFINITY;
-            release = !(__int_as_float(pbits) > theta) && (__int_as_float(pbits) < B || B == INFINITY);
+            const float hd = P.focused ? tile_heuristic(P, m, t / P.TY, t % P.TY) : 0.0f;
+            release = !(__int_as_float(pbits) > theta) && (__int_as_float(pbits) + hd < B || B == INFINITY);
         } else {
             release = !(__int_as_float(pbits) > (rbound < 0.0f ? P.ctr->rbound : rbound));
         }
@@ -618,7 +632,7 @@ __global__ void k_queue_min(DevParams P, int qz, int k) {
 }
 // invalidation bound for this step: the current start key plus one ordering band
 // start of a step with a single map: counters, start elements and the consume flag in one launch
-struct StepBegin { int start[4]; int consume; int clear_lmax; };
+struct StepBegin { int start[4]; int consume; int clear_lmax; float sx, sy; };
 __global__ void k_step_begin(DevParams P, StepBegin a) {
     const int t = threadIdx.x;
     if (t == 0) {
@@ -627,6 +641,7 @@ __global__ void k_step_begin(DevParams P, StepBegin a) {
         P.consume[0] = a.consume;
     }
     if (t < 4) P.start[t] = a.start[t];
+    if (t == 0) { P.spos[0] = a.sx; P.spos[1] = a.sy; }
     if (a.clear_lmax) for (int i = t; i < LMAX; i += blockDim.x) P.lmax[i] = 0;
 }
 __global__ void k_prepare_bound(DevParams P, float margin) {
@@ -762,7 +777,7 @@ struct Engine {
 
 void Engine::release() {
     if (!allocated) return;
-    hipFree(P.G); hipFree(P.Gprev); hipFree(P.cost); hipFree(P.goal); hipFree(P.cand); hipFree(P.queued); hipFree(P.prio); hipFree(P.start); hipFree(P.bnd);
+    hipFree(P.G); hipFree(P.Gprev); hipFree(P.cost); hipFree(P.goal); hipFree(P.cand); hipFree(P.queued); hipFree(P.prio); hipFree(P.start); hipFree(P.bnd); hipFree(P.spos);
     hipFree(P.touched); hipFree(P.tlist); hipFree(P.sflag); hipFree(P.slist); hipFree(P.slist2);
     hipFree(P.mark); hipFree(P.num_updated); hipFree(P.consume); hipFree(P.lmax); hipFree(P.ctr);
     hipFree(d_scratch);
@@ -796,6 +811,8 @@ int Engine::alloc(int width, int length) {
     HIPCHK(hipMalloc(&P.prio, sizeof(int) * 4 * P.NT));
     HIPCHK(hipMalloc(&P.start, sizeof(int) * 4 * nmaps));
     HIPCHK(hipMalloc(&P.bnd, sizeof(float) * nmaps));
+    HIPCHK(hipMalloc(&P.spos, sizeof(float) * 2 * nmaps));
+    HIPCHK(hipMemsetAsync(P.spos, 0, sizeof(float) * 2 * nmaps, stream));
     HIPCHK(hipMemsetAsync(P.start, 0xFF, sizeof(int) * 4 * nmaps, stream));
     HIPCHK(hipMalloc(&P.touched, sizeof(int) * P.NT));
     HIPCHK(hipMalloc(&P.tlist, sizeof(int) * P.NT));
@@ -939,6 +956,7 @@ int Engine::step(ufm_stats *out) {
         if (profiling) HIPCHK(hipMemsetAsync(P.lmax, 0, sizeof(int) * LMAX, stream));
     }
     P.focused = focused ? 1 : 0;
+    P.hm = heur ? heuristic_multiplier : 0.0f;
 
     // classify maps: (re)initialise, propagate pending patches, or idle  (ReplannerBase.h:48-59)
     int n_init = 0, n_upd = 0;
@@ -972,11 +990,16 @@ int Engine::step(ufm_stats *out) {
     }
     {   // start elements: the 4 corners of the start cell (FD impl:9-13, Cell.cpp:48-60) / the start cell (DFM)
         int *st_el = h_scratch + 5 * nmaps + 4;
+        float *sp = reinterpret_cast<float *>(h_scratch + 9 * nmaps + 8);
         for (int m = 0; m < nmaps; ++m) {
             const MapState &ms = maps[m];
             for (int i = 0; i < 4; ++i) st_el[4 * m + i] = -1;
+            sp[2 * m] = sp[2 * m + 1] = 0.0f;
             if (!ms.start_set) continue;
             const int cx = (int)std::roundf(ms.start_x), cy = (int)std::roundf(ms.start_y);
+            // keys measure from start_pos_ (FD/SG, Position::distance) or from start_cell_ (DFM, Cell::distance)
+            sp[2 * m] = (algo == UFM_ALGO_DFM) ? (float)cx : ms.start_x;
+            sp[2 * m + 1] = (algo == UFM_ALGO_DFM) ? (float)cy : ms.start_y;
             const int ncorner = (algo == UFM_ALGO_DFM) ? 1 : 4;
             for (int i = 0; i < ncorner; ++i) {
                 const int ex = cx + (i & 1), ey = cy + (i >> 1);
@@ -988,9 +1011,11 @@ int Engine::step(ufm_stats *out) {
             for (int i = 0; i < 4; ++i) sb.start[i] = st_el[i];
             sb.consume = consume[0];
             sb.clear_lmax = profiling ? 1 : 0;
+            sb.sx = sp[0]; sb.sy = sp[1];
             k_step_begin<<<1, 256, 0, stream>>>(P, sb);
         } else {
             HIPCHK(hipMemcpyAsync(P.start, st_el, sizeof(int) * 4 * nmaps, hipMemcpyHostToDevice, stream));
+            HIPCHK(hipMemcpyAsync(P.spos, sp, sizeof(float) * 2 * nmaps, hipMemcpyHostToDevice, stream));
         }
     }
     uint64_t updated = 0;
@@ -1183,7 +1208,7 @@ int engine_create(Engine **out, int n_maps, int algo, int opt_lvl, int use_heuri
     e->grid_relax = prop.multiProcessorCount * 2;
     HIPCHK(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
     HIPCHK(hipHostMalloc(&e->h_ctr, sizeof(DevCounters)));
-    HIPCHK(hipHostMalloc(&e->h_scratch, sizeof(int) * (9 * n_maps + 8)));
+    HIPCHK(hipHostMalloc(&e->h_scratch, sizeof(int) * (11 * n_maps + 16)));
     HIPCHK(hipHostMalloc(&e->h_bnd, sizeof(float) * n_maps));
     *out = e;
     return UFM_OK;
