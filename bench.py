@@ -61,7 +61,7 @@ def main():
     ap.add_argument("--patches", type=int, default=100)
     ap.add_argument("--algo", default="FD", choices=["FD", "SG", "DFM"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-size", type=int, default=1024)
+    ap.add_argument("--cpu-size", type=int, default=4096, help="map size of the CPU baseline sample (4096 = the identical workload, ~5 s)")
     ap.add_argument("--no-profile", action="store_true", help="skip per-launch HIP event timing")
     args = ap.parse_args()
 
