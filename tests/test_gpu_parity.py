@@ -16,7 +16,8 @@ def test_first_plan_reference_bitmaps(ref_bitmaps, algo, bitmap):
     assert o.step() == 0
     assert g.step() == 0
     n, nbad = check_parity(o, g, "%s/%s" % (algo, bitmap))
-    assert nbad == 0, "%d of %d trusted elements not bit-equal" % (nbad, n)
+    if algo != "DFM":   # DFM: tolerance (check_parity), its float fixed point is not unique
+        assert nbad == 0, "%d of %d trusted elements not bit-equal" % (nbad, n)
     g.close()
 
 
@@ -29,7 +30,8 @@ def test_first_plan_synthetic(algo, size):
     o, g = make_pair(ALGOS[algo], 0, cost, start, goal)
     assert o.step() == 0 and g.step() == 0
     n, nbad = check_parity(o, g, "%s/%dx%d" % (algo, width, length))
-    assert nbad == 0, "%d of %d trusted elements not bit-equal" % (nbad, n)
+    if algo != "DFM":
+        assert nbad == 0, "%d of %d trusted elements not bit-equal" % (nbad, n)
     # the engine counts every element it finalised; the oracle's expansions are a subset
     assert g.num_nodes_expanded >= n
     g.close()
@@ -132,7 +134,10 @@ def test_focused_and_full_field_agree_below_the_start_key(algo):
         key = gu[sx, sy] if algo == "DFM" else max(gu[sx, sy], gu[sx + 1, sy], gu[sx, sy + 1], gu[sx + 1, sy + 1])
         m = gu < key
         assert m.sum() > 100
-        assert np.array_equal(gf[m], gu[m]), "replan %d: %d differ" % (k, int((gf[m] != gu[m]).sum()))
+        if algo == "DFM":   # tolerance: the float fixed point of the DFM quadratic is not unique
+            assert np.all(np.abs(gf[m].astype(np.float64) - gu[m]) <= 1e-6 * gu[m])
+        else:
+            assert np.array_equal(gf[m], gu[m]), "replan %d: %d differ" % (k, int((gf[m] != gu[m]).sum()))
     assert work[0] < work[1]          # focusing must save work
     for p in ps:
         p.close()
@@ -266,4 +271,20 @@ def test_heuristic_keys(algo, lvl):
         n, nbad = check_parity(o, g, "%s heuristic replan %d" % (algo, k), below_start_key=True)
         if algo != "DFM":
             assert nbad == 0, (k, nbad, n)
+    g.close()
+
+
+@pytest.mark.parametrize("algo,size", [("FD", 1024), ("SG", 1024), ("DFM", 1024), ("DFM", 2048)])
+def test_first_plan_large(algo, size):
+    """Larger maps (the oracle still finishes in seconds): FD / SG bit-equal; DFM within 1e-6 --
+    including the 2048^2 map on which the DFM quadratic's ulp-level creep used to take 100 k launches."""
+    cost = ufm_amd.synth.cost_map(1000, size, size)
+    start, goal = ufm_amd.synth.start_goal(size, size)
+    o, g = make_pair(ALGOS[algo], 1 if algo != "SG" else 2, cost, start, goal)
+    assert o.step() == 0 and g.step() == 0
+    assert g.stats.launches < 4000
+    n, nbad = check_parity(o, g, "%s/%d" % (algo, size))
+    assert n > 0.9 * size * size
+    if algo != "DFM":
+        assert nbad == 0
     g.close()
