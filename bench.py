@@ -63,6 +63,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-size", type=int, default=4096, help="map size of the CPU baseline sample (4096 = the identical workload, ~5 s)")
     ap.add_argument("--no-profile", action="store_true", help="skip per-launch HIP event timing")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="collective backend for N > 1 (nccl = RCCL; gloo only to rehearse the control flow, staging through host memory)")
     args = ap.parse_args()
 
     import torch
@@ -71,15 +73,19 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # one process per GPU; (a gloo rehearsal on a single-GPU box folds the ranks onto the devices there are)
+    dev_index = local_rank % max(1, torch.cuda.device_count())
+    torch.cuda.set_device(dev_index)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
+        else:
+            dist.init_process_group("gloo")
     else:
         dist = None
-        torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    dev = torch.device("cuda", dev_index)
 
     size, seed = args.size, 7
     algo = {"FD": ufm_amd.ALGO_FD, "SG": ufm_amd.ALGO_SG, "DFM": ufm_amd.ALGO_DFM}[args.algo]
@@ -95,7 +101,7 @@ def main():
         d_patches = torch.empty((max(1, len(script)), psz, psz), dtype=torch.uint8, device=dev)
     d_recv = torch.empty((psz, psz), dtype=torch.uint8, device=dev)
 
-    planner = ufm_amd.Planner(algo, 1 if algo != ufm_amd.ALGO_SG else 2, False, device=local_rank)
+    planner = ufm_amd.Planner(algo, 1 if algo != ufm_amd.ALGO_SG else 2, False, device=dev_index)
     planner.set_occupancy_threshold(1)
     planner.set_profiling(not args.no_profile)
 
@@ -139,7 +145,7 @@ def main():
 
     if rank == 0:
         out = {
-            "metric": "grid cells updated/sec (full plan + 100 replans), 4096^2 map",
+            "metric": "grid cells updated/sec (full plan + 100 replans), %d^2 map" % size,
             "value": cells_all / dt,
             "unit": "cells/s",
             "n_gpus": world,
@@ -178,7 +184,7 @@ def main():
                 "kernel_time_share": kms * 1e-3 / dt,
                 "note": "latency-bound (dependent in-LDS sweeps along the wavefront), not bandwidth-bound: see DESIGN.md",
             }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:   # the CPU baseline is reported at N = 1 only
             out["cpu_baseline"] = cpu_baseline(args.cpu_size, seed, args.patches)
         print(json.dumps(out))
     if dist is not None:
