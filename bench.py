@@ -21,8 +21,9 @@ sys.path.insert(0, ROOT)
 
 import numpy as np  # noqa: E402
 
-TILE = 32
-BYTES_PER_TILE_VISIT = 9 * TILE * TILE + (4 * TILE + 4) * 4   # 9 B/element + halo
+def bytes_per_tile_visit(tile):
+    """9 B per element relaxation (4 B G read + 1 B cost + 4 B G write) + the halo"""
+    return 9 * tile * tile + (4 * tile + 4) * 4
 HBM_PEAK_GBS = 8000.0                                         # MI355X_MICROARCH.md: HBM3E peak
 
 
@@ -69,6 +70,7 @@ def main():
 
     import torch
     import ufm_amd
+    BYTES_PER_TILE_VISIT = bytes_per_tile_visit(ufm_amd.load_library().ufm_tile_edge())
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))

@@ -107,6 +107,7 @@ int ufm_set_param(ufm_t *p, const char *name, double value);
 int ufm_set_profiling(ufm_t *p, int enable);   /* HIP-event timing of every relax launch */
 void *ufm_stream(ufm_t *p);                    /* hipStream_t the kernels run on */
 const char *ufm_version(void);
+int ufm_tile_edge(void);                       /* elements per tile side (for the algorithmic-bytes accounting) */
 
 /* ---- batch of independent map instances on one device (BASELINE config 4).
  * Every map of the batch has the same size / algo; a batch step advances all

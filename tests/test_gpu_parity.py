@@ -221,9 +221,10 @@ def test_batch_of_independent_maps():
         oracles.append(o)
     assert b.step() == 0
     for i, o in enumerate(oracles):
-        m = o.trusted_mask()
+        m = o.trusted_mask(below_start_key=True)   # what a planner honouring end_condition must have finalised
         a, ref = b.read_field(i)[m], o.g()[m]
-        assert np.all(np.abs(a.astype(np.float64) - ref) <= 1e-6 * ref)
+        assert m.sum() > 10000
+        assert np.all(np.abs(a.astype(np.float64) - ref) <= 2e-6 * ref)
     # patch two of the maps, leave the others alone
     for i in (1, 3):
         patch = np.full((9, 9), 3 + i, dtype=np.uint8)
@@ -232,9 +233,10 @@ def test_batch_of_independent_maps():
         assert oracles[i].step() == 0
     assert b.step() == 0
     for i, o in enumerate(oracles):
-        m = o.trusted_mask()
+        m = o.trusted_mask(below_start_key=True)
         a, ref = b.read_field(i)[m], o.g()[m]
-        assert np.all(np.abs(a.astype(np.float64) - ref) <= 1e-6 * ref), i
+        err = np.abs(a.astype(np.float64) - ref)
+        assert np.all(err <= 2e-6 * ref), (i, float(err.max()), int(m.sum()))
     b.close()
 
 

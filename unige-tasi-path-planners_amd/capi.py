@@ -17,7 +17,7 @@ SYMBOLS = [
     "ufm_set_heuristic_multiplier", "ufm_set_map", "ufm_patch_map", "ufm_set_start",
     "ufm_set_goal", "ufm_step", "ufm_set_map_device", "ufm_patch_map_device",
     "ufm_field_dims", "ufm_read_field", "ufm_read_map", "ufm_set_param", "ufm_set_profiling", "ufm_stream",
-    "ufm_version", "ufm_batch_create", "ufm_batch_destroy", "ufm_batch_size",
+    "ufm_version", "ufm_tile_edge", "ufm_batch_create", "ufm_batch_destroy", "ufm_batch_size",
     "ufm_batch_set_occupancy_threshold", "ufm_batch_set_map", "ufm_batch_patch_map",
     "ufm_batch_set_start", "ufm_batch_set_goal", "ufm_batch_reset", "ufm_batch_step",
     "ufm_batch_read_field",

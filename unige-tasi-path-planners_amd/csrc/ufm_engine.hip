@@ -33,9 +33,16 @@
 
 namespace {
 
-constexpr int T = 32;          // tile edge (elements)
-constexpr int GP = 40;         // LDS pitch of the G tile: rows 8 apart hit distinct banks
-constexpr int CP = 34;         // LDS pitch of the cost tile
+#ifndef UFM_TILE
+#define UFM_TILE 16
+#endif
+constexpr int T = UFM_TILE;    // tile edge (elements): 32 or 16
+static_assert(T == 32 || T == 16, "tile edge must be 32 or 16");
+constexpr int GP = T + 8;      // LDS pitch of the G tile: rows 4 apart land on distinct banks
+constexpr int CP = T + 2;      // LDS pitch of the cost tile
+constexpr int PT = T / 4;      // 4x4-node patches per tile side
+constexpr int PR = PT / 4;     // patches per wave per side (the 16 waves form a 4x4 grid)
+constexpr int PPW = PR * PR;   // patches per wave: 4 (T = 32) or 1 (T = 16)
 constexpr int NTHR = 1024;     // one element per lane, 16 waves, each owns an 8x8 patch
 #ifndef UFM_IDLE_SLEEP
 #define UFM_IDLE_SLEEP 4
@@ -57,6 +64,9 @@ enum { Q_LOWER = 0, Q_RAISE = 1 };
 struct DevCounters {
     int cnt[2][3];              // [queue][ring]: candidate-list lengths (ring of three, see k_relax)
     int rel[2][3];              // [queue][ring]: tiles released (relaxed) by the launch that read the list
+    int lmin[2][3];             // [queue][ring]: smallest priority ever queued in the list (float bits)
+    int nready[2];              // [launch parity]: length of the ready list k_triage built
+    int rcursor[2];             // [launch parity]: next ready entry to hand to a workgroup
     int tcount;                 // touched-list length
     int scount;                 // pending-seed-list length (survives steps)
     unsigned long long expanded;
@@ -77,6 +87,7 @@ struct DevParams {
     uint8_t *cost;              // [nmaps][L][W]
     int *goal;                  // [nmaps][2]
     int *cand;                  // [2 queues][3][NT] queued tiles (global tile ids), ring of three lists
+    int *ready;                 // [NT] tiles released by k_triage for the following relax launch
     int *queued;                // [2 queues][2][NT] tile is in the candidate list of that launch parity
     int *prio;                  // [2 queues][2][NT] float bits: smallest value that entered the tile since its last visit
     int *start;                 // [nmaps][4] start elements (linear index in the map, -1 unused)
@@ -105,8 +116,11 @@ struct DevParams {
 };
 
 // queue tile gt in queue qz for the launch that reads list `lst` / priority parity `par`
-__device__ __forceinline__ void activate(const DevParams &P, int qz, int lst, int par, int gt, int pbits) {
+// (`banded` = false for an entry that is only parked beyond the start's key: it must not hold the
+// ordering band of the other entries -- of other maps in a batch -- down)
+__device__ __forceinline__ void activate(const DevParams &P, int qz, int lst, int par, int gt, int pbits, bool banded = true) {
     atomicMin(&P.prio[(qz * 2 + par) * P.NT + gt], pbits);
+    if (banded) atomicMin(&P.ctr->lmin[qz][lst], pbits);
     if (atomicExch(&P.queued[(qz * 2 + par) * P.NT + gt], 1) == 0) {
         const int k = atomicAdd(&P.ctr->cnt[qz][lst], 1);
         P.cand[(qz * 3 + lst) * P.NT + k] = gt;
@@ -297,25 +311,33 @@ __device__ __forceinline__ float cell_cost(const DevParams &P, const uint8_t *cm
 //     sweep 4x4-node patches asynchronously (wake bits in LDS, no workgroup barrier per sweep),
 //     written back, and the neighbours whose halo changed are queued with the smallest changed
 //     value as priority.
-template <int ALGO, int MODE>
-__global__ __launch_bounds__(NTHR) void k_relax(DevParams P, int k, float delta, float rbound, int max_sweeps) {
+// DYN: the tiles come from the ready list k_triage built (taken through an atomic cursor: perfect
+// balance, used while the queue is long); !DYN: triage fused as described above (short queues).
+template <int ALGO, int MODE, bool DYN>
+__global__ __launch_bounds__(NTHR, (T == 16) ? 8 : 4) void k_relax(DevParams P, int k, float delta, float rbound, int max_sweeps) {
     __shared__ float Gs[(T + 2) * GP];
     __shared__ float Cs[(T + 1) * CP];
-    __shared__ int s_wake[16];  // per wave: bit j = patch j of the wave has new inputs
+    __shared__ int s_wake[16];  // per wave: bit j = patch j of the wave has new inputs (PPW bits)
     __shared__ int s_idle;      // waves currently without work
     __shared__ int s_giveup;    // a wave hit the sweep cap: end the visit, re-queue the tile
     __shared__ int s_misc[4];   // 0: first touch, 1: earlier visits in this step, 2: patch sweeps (sum), 3: (max per wave)
     __shared__ int s_bmin[9];   // per direction: smallest changed value on that border (float bits)
     __shared__ int s_min;
+    __shared__ float s_B[64];   // fused triage: start key of the first 64 maps
 
     const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
     const int q = lane & 3, nd = lane >> 2;                    // quad lane, node within the 4x4 patch
     const int wr = w >> 2, wc = w & 3;                         // the wave's 8x8 region = 2x2 patches
-    const int io_r = tid >> 5, io_c = tid & 31;                // HBM mapping
+    const int io_r = tid / T, io_c = tid % T;                  // HBM mapping (threads tid < T*T)
+    const bool io_on = tid < T * T;
     constexpr int Q = (MODE == MODE_LOWER) ? Q_LOWER : Q_RAISE;
     const int r = k % 3, rn = (k + 1) % 3, rz = (k + 2) % 3, pc = k & 1, pn = pc ^ 1;
-    const int n = P.ctr->cnt[Q][r];
-    if (blockIdx.x == 0 && tid == 0) { P.ctr->cnt[Q][rz] = 0; P.ctr->rel[Q][rz] = 0; }
+    const int n = DYN ? P.ctr->nready[k & 1] : P.ctr->cnt[Q][r];
+    if (blockIdx.x == 0 && tid == 0) {
+        P.ctr->cnt[Q][rz] = 0; P.ctr->rel[Q][rz] = 0; P.ctr->lmin[Q][rz] = INFBITS;
+        P.ctr->nready[(k + 1) & 1] = 0; P.ctr->rcursor[(k + 1) & 1] = 0;   // for the next triage
+        if (DYN) P.ctr->rel[Q][r] = n;
+    }
     if (n == 0) return;
     const int *cand = P.cand + (size_t)(Q * 3 + r) * P.NT;
     int *prio = P.prio + (size_t)(Q * 2 + pc) * P.NT;
@@ -324,10 +346,15 @@ __global__ __launch_bounds__(NTHR) void k_relax(DevParams P, int k, float delta,
     constexpr int COFF = (ALGO == UFM_ALGO_DFM) ? 0 : 1;
 
     if (tid == 0) s_min = INFBITS;
+    if (!DYN && tid < 64) s_B[tid] = (MODE == MODE_LOWER && P.focused && tid < P.nmaps) ? start_bound(P, tid) : INFINITY;
     __syncthreads();
-    {
+    if (!DYN) {   // smallest priority among the entries that are not parked beyond their map's start key
         int lmin = INFBITS;
-        for (int i = tid; i < n; i += NTHR) lmin = min(lmin, prio[cand[i]]);
+        for (int i = tid; i < n; i += NTHR) {
+            const int c = cand[i], pb = prio[c], mm = c / P.NTm;
+            const float Bm = mm < 64 ? s_B[mm] : INFINITY;
+            if (__int_as_float(pb) < Bm || Bm == INFINITY) lmin = min(lmin, pb);
+        }
         if (lmin != INFBITS) atomicMin(&s_min, lmin);
     }
     __syncthreads();
@@ -344,27 +371,37 @@ __global__ __launch_bounds__(NTHR) void k_relax(DevParams P, int k, float delta,
     }
     const int colour = ((nd >> 2) & 1) | ((nd & 1) << 1);
 
-    for (int i = blockIdx.x; i < n; i += gridDim.x) {
-        const int gt = cand[i];
-        const int pbits = prio[gt];
+    for (int i = blockIdx.x;; i += gridDim.x) {
+        if (DYN) {                                         // next ready tile, whoever is free takes it
+            __syncthreads();
+            if (tid == 0) s_min = atomicAdd(&P.ctr->rcursor[k & 1], 1);
+            __syncthreads();
+            i = s_min;
+        }
+        if (i >= n) break;
+        const int gt = DYN ? P.ready[i] : cand[i];
+        const int pbits = DYN ? 0 : prio[gt];
         const int m = gt / P.NTm, t = gt - m * P.NTm;
         // lowering: release within the ordering band and below the start's key (end condition);
         // invalidation: release below the bound the host derived from the start's key
-        bool release;
-        if (MODE == MODE_LOWER) {
-            const float B = P.focused ? start_bound(P, m) : INFINITY;
-            const float hd = P.focused ? tile_heuristic(P, m, t / P.TY, t % P.TY) : 0.0f;
-            release = !(__int_as_float(pbits) > theta) && (__int_as_float(pbits) + hd < B || B == INFINITY);
-        } else {
-            release = !(__int_as_float(pbits) > (rbound < 0.0f ? P.ctr->rbound : rbound));
+        if (!DYN) {
+            bool release, parked = false;
+            if (MODE == MODE_LOWER) {
+                const float B = P.focused ? start_bound(P, m) : INFINITY;
+                const float hd = P.focused ? tile_heuristic(P, m, t / P.TY, t % P.TY) : 0.0f;
+                parked = !(__int_as_float(pbits) + hd < B || B == INFINITY);
+                release = !(__int_as_float(pbits) > theta) && !parked;
+            } else {
+                release = !(__int_as_float(pbits) > (rbound < 0.0f ? P.ctr->rbound : rbound));
+            }
+            __syncthreads();                               // everyone holds pbits; LDS of the previous tile is free
+            if (tid == 0) { queued[gt] = 0; prio[gt] = INFBITS; }
+            if (!release) {                                // not yet: carry over
+                if (tid == 0) activate(P, Q, rn, pn, gt, pbits, !parked);
+                continue;
+            }
+            if (tid == 0) atomicAdd(&P.ctr->rel[Q][r], 1);
         }
-        __syncthreads();                                   // everyone holds pbits; LDS of the previous tile is free
-        if (tid == 0) { queued[gt] = 0; prio[gt] = INFBITS; }
-        if (!release) {                                    // not yet: carry over
-            if (tid == 0) activate(P, Q, rn, pn, gt, pbits);
-            continue;
-        }
-        if (tid == 0) atomicAdd(&P.ctr->rel[Q][r], 1);
         const int tx = t / P.TY, ty = t - tx * P.TY;
         const int x0 = tx * T, y0 = ty * T;
         float *Gm = P.G + (size_t)m * P.gstride;
@@ -376,21 +413,24 @@ __global__ __launch_bounds__(NTHR) void k_relax(DevParams P, int k, float delta,
             if (first) P.tlist[atomicAdd(&P.ctr->tcount, 1)] = gt;
             s_misc[0] = first; s_misc[1] = seen; s_misc[2] = 0; s_misc[3] = 0; s_idle = 0; s_giveup = 0;
         }
-        if (tid < 16) s_wake[tid] = 0xF;
+        if (tid < 16) s_wake[tid] = (1 << PPW) - 1;
         if (tid >= 32 && tid < 41) s_bmin[tid - 32] = INFBITS;
 
         // stage G tile + halo (rows padded by one, columns by GPAD: no bounds checks)
-        const size_t gidx = (size_t)(x0 + io_r + 1) * P.pitch + (y0 + io_c + GPAD);
-        const float gl0 = Gm[gidx];
-        Gs[(io_r + 1) * GP + io_c + 1] = gl0;
-        if (tid < 4 * T + 4) {
-            int hr, hc;
-            if (tid < T) { hr = -1; hc = tid; }
-            else if (tid < 2 * T) { hr = T; hc = tid - T; }
-            else if (tid < 3 * T) { hr = tid - 2 * T; hc = -1; }
-            else if (tid < 4 * T) { hr = tid - 3 * T; hc = T; }
-            else { hr = (tid & 2) ? T : -1; hc = (tid & 1) ? T : -1; }
-            Gs[(hr + 1) * GP + hc + 1] = Gm[(size_t)(x0 + hr + 1) * P.pitch + (y0 + hc + GPAD)];
+        const size_t gidx = io_on ? (size_t)(x0 + io_r + 1) * P.pitch + (y0 + io_c + GPAD) : 0;
+        float gl0 = 0.0f;
+        if (io_on) { gl0 = Gm[gidx]; Gs[(io_r + 1) * GP + io_c + 1] = gl0; }
+        {   // halo: the last 4T+4 threads of the workgroup (for T = 16 they are otherwise idle here)
+            const int ht = tid - (NTHR - (4 * T + 4));
+            if (ht >= 0) {
+                int hr, hc;
+                if (ht < T) { hr = -1; hc = ht; }
+                else if (ht < 2 * T) { hr = T; hc = ht - T; }
+                else if (ht < 3 * T) { hr = ht - 2 * T; hc = -1; }
+                else if (ht < 4 * T) { hr = ht - 3 * T; hc = T; }
+                else { hr = (ht & 2) ? T : -1; hc = (ht & 1) ? T : -1; }
+                Gs[(hr + 1) * GP + hc + 1] = Gm[(size_t)(x0 + hr + 1) * P.pitch + (y0 + hc + GPAD)];
+            }
         }
         // stage the cost tile as float (inf = obstacle / outside)
         for (int e = tid; e < CROWS * CROWS; e += NTHR) {
@@ -398,22 +438,22 @@ __global__ __launch_bounds__(NTHR) void k_relax(DevParams P, int k, float delta,
             Cs[cr * CP + cc] = cell_cost(P, cm, x0 + cr - COFF, y0 + cc - COFF);
         }
         __syncthreads();
-        if (s_misc[0]) P.Gprev[(size_t)m * P.gstride + gidx] = gl0;
+        if (s_misc[0] && io_on) P.Gprev[(size_t)m * P.gstride + gidx] = gl0;
 
         // per-lane constants of the wave's four patches
-        QuadConsts<ALGO> C[4];
-        int off[4], wword[4], wbit[4];
-        bool goal[4];
+        QuadConsts<ALGO> C[PPW];
+        int off[PPW], wword[PPW], wbit[PPW];
+        bool goal[PPW];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int lx = wr * 8 + (j >> 1) * 4 + (nd >> 2), ly = wc * 8 + (j & 1) * 4 + (nd & 3);
+        for (int j = 0; j < PPW; ++j) {
+            const int lx = (wr * PR + j / PR) * 4 + (nd >> 2), ly = (wc * PR + j % PR) * 4 + (nd & 3);
             C[j].load(Cs, lx, ly, q);
             off[j] = (lx + 1) * GP + ly + 1;
             goal[j] = (x0 + lx == P.goal[2 * m]) && (y0 + ly == P.goal[2 * m + 1]);
             wword[j] = 0; wbit[j] = 0;
             if (lane < 9) {
-                const int gr = wr * 2 + (j >> 1) + lane / 3 - 1, gc = wc * 2 + (j & 1) + lane % 3 - 1;   // 8x8 patch grid
-                if (gr >= 0 && gr < 8 && gc >= 0 && gc < 8) { wword[j] = (gr >> 1) * 4 + (gc >> 1); wbit[j] = 1 << ((gr & 1) * 2 + (gc & 1)); }
+                const int gr = wr * PR + j / PR + lane / 3 - 1, gc = wc * PR + j % PR + lane % 3 - 1;   // PT x PT patch grid
+                if (gr >= 0 && gr < PT && gc >= 0 && gc < PT) { wword[j] = (gr / PR) * 4 + (gc / PR); wbit[j] = 1 << ((gr % PR) * PR + (gc % PR)); }
             }
         }
 
@@ -428,7 +468,7 @@ __global__ __launch_bounds__(NTHR) void k_relax(DevParams P, int k, float delta,
         // transient neighbours.  Two neighbours that feed each other can flip-flop forever if they
         // rise in the same sweep, so an element may only rise in sweeps of its own colour
         // (4-colouring: no two 8-neighbours share one).
-        int cnt[4] = {0, 0, 0, 0};
+        int cnt[PPW] = {};
         int tot = 0;
         const bool lax = (ALGO == UFM_ALGO_DFM) && (s_misc[1] > 16);
         bool conv = false;
@@ -439,7 +479,7 @@ __global__ __launch_bounds__(NTHR) void k_relax(DevParams P, int k, float delta,
             bool vote = __hip_atomic_load(&s_giveup, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != 0;
             if (bits && !vote) {
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
+                for (int j = 0; j < PPW; ++j) {
                     if (!(bits & (1 << j))) continue;    // wave-uniform
                     float *ctr = Gs + off[j];
                     bool again = true;
@@ -478,7 +518,7 @@ __global__ __launch_bounds__(NTHR) void k_relax(DevParams P, int k, float delta,
                     if (again && lane == 0)              // burst cap: leave the rest to the next take
                         __hip_atomic_fetch_or(&s_wake[w], 1 << j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 }
-                if (tot >= 4 * max_sweeps && lane == 0)  // give up this visit; the tile is re-queued
+                if (tot >= PPW * max_sweeps && lane == 0)  // give up this visit; the tile is re-queued
                     __hip_atomic_store(&s_giveup, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 continue;
             }
@@ -510,7 +550,7 @@ __global__ __launch_bounds__(NTHR) void k_relax(DevParams P, int k, float delta,
         __syncthreads();
 
         // write back what changed; note which neighbours saw their halo change
-        const float gf = Gs[(io_r + 1) * GP + io_c + 1];
+        const float gf = io_on ? Gs[(io_r + 1) * GP + io_c + 1] : gl0;
         if (gf != gl0) {
             Gm[gidx] = gf;
             // DFM only: the float fixed point of the upwind quadratic is not unique;
@@ -548,6 +588,38 @@ __global__ __launch_bounds__(NTHR) void k_relax(DevParams P, int k, float delta,
                 if (ntx >= 0 && ntx < P.TX && nty >= 0 && nty < P.TY) activate(P, Q, rn, pn, m * P.NTm + ntx * P.TY + nty, s_bmin[tid]);
             }
         }
+    }
+}
+
+// Vectorised triage for long queues: one thread per queued tile decides "release now" (append to
+// the ready list of the following relax launch) or "carry over" (same list ring as k_relax).
+template <int MODE>
+__global__ void k_triage(DevParams P, int k, float delta, float rbound) {
+    constexpr int Q = (MODE == MODE_LOWER) ? Q_LOWER : Q_RAISE;
+    const int r = k % 3, rn = (k + 1) % 3, pc = k & 1, pn = pc ^ 1;
+    const int n = P.ctr->cnt[Q][r];
+    const int *cand = P.cand + (size_t)(Q * 3 + r) * P.NT;
+    int *prio = P.prio + (size_t)(Q * 2 + pc) * P.NT;
+    int *queued = P.queued + (size_t)(Q * 2 + pc) * P.NT;
+    const float theta = __int_as_float(P.ctr->lmin[Q][r]) + delta;
+    const float rb = (rbound < 0.0f) ? P.ctr->rbound : rbound;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const int gt = cand[i];
+        const int pbits = prio[gt];
+        const int m = gt / P.NTm, t = gt - m * P.NTm;
+        bool release, parked = false;
+        if (MODE == MODE_LOWER) {
+            const float B = P.focused ? start_bound(P, m) : INFINITY;
+            const float hd = P.focused ? tile_heuristic(P, m, t / P.TY, t % P.TY) : 0.0f;
+            parked = !(__int_as_float(pbits) + hd < B || B == INFINITY);
+            release = !(__int_as_float(pbits) > theta) && !parked;
+        } else {
+            release = !(__int_as_float(pbits) > rb);
+        }
+        queued[gt] = 0;
+        prio[gt] = INFBITS;
+        if (release) P.ready[atomicAdd(&P.ctr->nready[k & 1], 1)] = gt;
+        else activate(P, Q, rn, pn, gt, pbits, !parked);
     }
 }
 
@@ -712,16 +784,16 @@ __global__ void k_cost_stats(const uint8_t *cm, size_t n, int thr, unsigned long
     if ((threadIdx.x & 63) == 0) { atomicAdd(&out[0], s); atomicAdd(&out[1], c); }
 }
 // count elements whose G differs from the snapshot taken at first touch; release the tiles
-__global__ __launch_bounds__(NTHR) void k_finalize(DevParams P, int only_if_done) {
+__global__ __launch_bounds__(T * T) void k_finalize(DevParams P, int only_if_done) {
     if (only_if_done && !P.ctr->done) return;
     const int n = P.ctr->tcount;
-    const int io_r = threadIdx.x >> 5, io_c = threadIdx.x & 31;
+    const int io_r = threadIdx.x / T, io_c = threadIdx.x % T;
     for (int i = blockIdx.x; i < n; i += gridDim.x) {
         const int gt = P.tlist[i];
         const int m = gt / P.NTm, t = gt - m * P.NTm;
         const int tx = t / P.TY, ty = t - tx * P.TY;
         const size_t gidx = (size_t)m * P.gstride + (size_t)(tx * T + io_r + 1) * P.pitch + (ty * T + io_c + GPAD);
-        const int diff = P.G[gidx] != P.Gprev[gidx];
+        const int diff = (threadIdx.x < T * T) && (P.G[gidx] != P.Gprev[gidx]);
         const int c = __syncthreads_count(diff);
         if (threadIdx.x == 0) {
             if (c) atomicAdd(&P.ctr->expanded, (unsigned long long)c);
@@ -772,8 +844,10 @@ struct Engine {
     std::vector<uint64_t> upd_pending;   // per map
     int iter[2] = {0, 0};            // index k of the next relax launch of each queue (never reset: the queues persist)
     bool focused = true;             // stop at the start's key like the reference (end_condition)
+    bool dynamic_mode = true;        // long queues: k_triage + cursor hand-out
     float *h_bnd = nullptr;          // pinned [nmaps]
     int hist_raise = 3, hist_lower = 4;   // blind batch sizes of the replan fast path
+    int last_active = 1;             // queue length at the last host check: long queues go through k_triage
     int grid_relax = 512;
     int max_iters = 32;              // sweep cap per tile visit (x4 patch sweeps per wave): a tile that needs more is
                                      // re-queued instead of holding the whole launch (measured optimum on 4096^2)
@@ -797,7 +871,7 @@ struct Engine {
 
 void Engine::release() {
     if (!allocated) return;
-    hipFree(P.G); hipFree(P.Gprev); hipFree(P.cost); hipFree(P.goal); hipFree(P.cand); hipFree(P.queued); hipFree(P.prio); hipFree(P.start); hipFree(P.bnd); hipFree(P.spos);
+    hipFree(P.G); hipFree(P.Gprev); hipFree(P.cost); hipFree(P.goal); hipFree(P.cand); hipFree(P.ready); hipFree(P.queued); hipFree(P.prio); hipFree(P.start); hipFree(P.bnd); hipFree(P.spos);
     hipFree(P.touched); hipFree(P.tlist); hipFree(P.sflag); hipFree(P.slist); hipFree(P.slist2);
     hipFree(P.mark); hipFree(P.num_updated); hipFree(P.consume); hipFree(P.lmax); hipFree(P.ctr);
     hipFree(d_scratch);
@@ -827,6 +901,7 @@ int Engine::alloc(int width, int length) {
     HIPCHK(hipMalloc(&P.cost, P.cstride * nmaps));
     HIPCHK(hipMalloc(&P.goal, sizeof(int) * 2 * nmaps));
     HIPCHK(hipMalloc(&P.cand, sizeof(int) * 6 * P.NT));
+    HIPCHK(hipMalloc(&P.ready, sizeof(int) * P.NT));
     HIPCHK(hipMalloc(&P.queued, sizeof(int) * 4 * P.NT));
     HIPCHK(hipMalloc(&P.prio, sizeof(int) * 4 * P.NT));
     HIPCHK(hipMalloc(&P.start, sizeof(int) * 4 * nmaps));
@@ -866,7 +941,9 @@ int Engine::alloc(int width, int length) {
 int Engine::reset_queues() {
     HIPCHK(hipMemsetAsync(P.queued, 0, sizeof(int) * 4 * P.NT, stream));
     k_fill<<<64, 256, 0, stream>>>(reinterpret_cast<float *>(P.prio), (size_t)4 * P.NT, INFINITY);
-    HIPCHK(hipMemsetAsync(P.ctr->cnt, 0, sizeof(int) * 12, stream));   // cnt + rel
+    HIPCHK(hipMemsetAsync(P.ctr->cnt, 0, sizeof(int) * 22, stream));   // cnt, rel, lmin, nready, rcursor
+    k_fill<<<1, 64, 0, stream>>>(reinterpret_cast<float *>(&P.ctr->lmin[0][0]), (size_t)6, INFINITY);
+    last_active = 1;
     iter[0] = iter[1] = 0;
     return UFM_OK;
 }
@@ -886,7 +963,14 @@ int Engine::launch_relax(int mode, float rbound) {
     // invalidation is order-free; lowering releases tiles in bands of `delta`
     const float delta = (mode == MODE_RAISE) ? INFINITY : (delta_abs >= 0.0f ? delta_abs : delta_scale * T * mean_cost);
     const int q = (mode == MODE_LOWER) ? Q_LOWER : Q_RAISE;
-#define UFM_LAUNCH(A, M) k_relax<A, M><<<g, b, 0, stream>>>(P, iter[q], delta, rbound, max_iters)
+    // long queue: vectorised triage + balanced hand-out of the released tiles; short queue: fused
+    const bool dyn = dynamic_mode && last_active > grid_relax / 4;
+    if (dyn) {
+        if (mode == MODE_LOWER) k_triage<MODE_LOWER><<<64, 256, 0, stream>>>(P, iter[q], delta, rbound);
+        else k_triage<MODE_RAISE><<<64, 256, 0, stream>>>(P, iter[q], delta, rbound);
+    }
+#define UFM_LAUNCH(A, M) do { if (dyn) k_relax<A, M, true><<<g, b, 0, stream>>>(P, iter[q], delta, rbound, max_iters); \
+                              else k_relax<A, M, false><<<g, b, 0, stream>>>(P, iter[q], delta, rbound, max_iters); } while (0)
     if (mode == MODE_LOWER) {
         if (algo == UFM_ALGO_FD) UFM_LAUNCH(UFM_ALGO_FD, MODE_LOWER);
         else if (algo == UFM_ALGO_SG) UFM_LAUNCH(UFM_ALGO_SG, MODE_LOWER);
@@ -936,6 +1020,7 @@ int Engine::run_phase(int mode, float rbound, uint32_t *launches, float *kernel_
                 *kernel_ms += ms;
             }
         const int active = h_ctr->cnt[q][iter[q] % 3];
+        last_active = active;
         if (active == 0) return UFM_OK;
         if (h_ctr->rel[q][(iter[q] + 2) % 3] == 0) return UFM_OK;   // the last launch released nothing
         if (total > cap) return UFM_ERR_NOT_CONVERGED;
@@ -1070,6 +1155,7 @@ int Engine::step(ufm_stats *out) {
             e0 = ev[0]; e1 = ev[1]; e2 = ev[2]; e3 = ev[3];
             HIPCHK(hipEventRecord(e0, stream));
         }
+        last_active = 1;             // replans touch a handful of tiles: fused triage
         for (int i = 0; i < nr; ++i) launch_relax(MODE_RAISE, -1.0f);
         if (profiling) HIPCHK(hipEventRecord(e1, stream));
         k_touched_to_active<<<64, 256, 0, stream>>>(P, Q_LOWER, iter[Q_LOWER]);
@@ -1077,7 +1163,7 @@ int Engine::step(ufm_stats *out) {
         for (int i = 0; i < nl; ++i) launch_relax(MODE_LOWER, INFINITY);
         if (profiling) HIPCHK(hipEventRecord(e3, stream));
         k_check<<<1, 1024, 0, stream>>>(P, iter[Q_RAISE], iter[Q_LOWER], band);
-        k_finalize<<<grid_relax, NTHR, 0, stream>>>(P, 1);
+        k_finalize<<<grid_relax, T * T, 0, stream>>>(P, 1);
         HIPCHK(hipMemcpyAsync(h_ctr, P.ctr, sizeof(DevCounters), hipMemcpyDeviceToHost, stream));
         HIPCHK(hipGetLastError());
         HIPCHK(hipStreamSynchronize(stream));
@@ -1177,7 +1263,7 @@ int Engine::step(ufm_stats *out) {
             if (!again) break;
         }
         const auto td = std::chrono::steady_clock::now();
-        k_finalize<<<grid_relax, NTHR, 0, stream>>>(P, 0);
+        k_finalize<<<grid_relax, T * T, 0, stream>>>(P, 0);
         HIPCHK(hipMemcpyAsync(h_ctr, P.ctr, sizeof(DevCounters), hipMemcpyDeviceToHost, stream));
         HIPCHK(hipStreamSynchronize(stream));
         st.expanded = h_ctr->expanded;
@@ -1333,7 +1419,8 @@ struct ufm_batch { Engine *e; };
 
 extern "C" {
 
-const char *ufm_version(void) { return "ufm-gfx950 0.1 (block-FIM, tile 32)"; }
+int ufm_tile_edge(void) { return T; }
+const char *ufm_version(void) { return T == 32 ? "ufm-gfx950 0.1 (block-FIM, tile 32)" : "ufm-gfx950 0.1 (block-FIM, tile 16)"; }
 
 int ufm_create(ufm_t **out, int algo, int opt_lvl, int use_heuristic, int device_id) {
     if (!out) return UFM_ERR_INVALID;
@@ -1396,6 +1483,7 @@ int ufm_set_param(ufm_t *p, const char *name, double value) {
     else if (!std::strcmp(name, "batch")) e->batch_fixed = (int)value;
     else if (!std::strcmp(name, "grid")) e->grid_relax = value < 1 ? 1 : (int)value;
     else if (!std::strcmp(name, "focused")) e->focused = value != 0.0;
+    else if (!std::strcmp(name, "dynamic")) e->dynamic_mode = value != 0.0;
     else return UFM_ERR_INVALID;
     return UFM_OK;
 }
