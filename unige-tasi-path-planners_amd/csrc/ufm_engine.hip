@@ -314,7 +314,7 @@ __device__ __forceinline__ float cell_cost(const DevParams &P, const uint8_t *cm
 // DYN: the tiles come from the ready list k_triage built (taken through an atomic cursor: perfect
 // balance, used while the queue is long); !DYN: triage fused as described above (short queues).
 template <int ALGO, int MODE, bool DYN>
-__global__ __launch_bounds__(NTHR, (T == 16) ? 8 : 4) void k_relax(DevParams P, int k, float delta, float rbound, int max_sweeps) {
+__global__ __launch_bounds__(NTHR) void k_relax(DevParams P, int k, float delta, float rbound, int max_sweeps) {
     __shared__ float Gs[(T + 2) * GP];
     __shared__ float Cs[(T + 1) * CP];
     __shared__ int s_wake[16];  // per wave: bit j = patch j of the wave has new inputs (PPW bits)
