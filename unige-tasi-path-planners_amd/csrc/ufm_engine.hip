@@ -861,7 +861,7 @@ struct Engine {
 
     int alloc(int width, int length);
     void release();
-    int launch_relax(int mode, float rbound);
+    int launch_relax(int mode, float rbound, hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr);
     int run_phase(int mode, float rbound, uint32_t *launches, float *kernel_ms);
     int reset_queues();
     int read_bounds(float *bmax);
@@ -958,7 +958,8 @@ int Engine::read_bounds(float *bmax) {
     return UFM_OK;
 }
 
-int Engine::launch_relax(int mode, float rbound) {
+// e0 / e1 (profiling): HIP events recorded on the engine's stream right around the relax kernel
+int Engine::launch_relax(int mode, float rbound, hipEvent_t e0, hipEvent_t e1) {
     const dim3 g(grid_relax), b(NTHR);
     // invalidation is order-free; lowering releases tiles in bands of `delta`
     const float delta = (mode == MODE_RAISE) ? INFINITY : (delta_abs >= 0.0f ? delta_abs : delta_scale * T * mean_cost);
@@ -969,6 +970,7 @@ int Engine::launch_relax(int mode, float rbound) {
         if (mode == MODE_LOWER) k_triage<MODE_LOWER><<<64, 256, 0, stream>>>(P, iter[q], delta, rbound);
         else k_triage<MODE_RAISE><<<64, 256, 0, stream>>>(P, iter[q], delta, rbound);
     }
+    if (e0) HIPCHK(hipEventRecord(e0, stream));
 #define UFM_LAUNCH(A, M) do { if (dyn) k_relax<A, M, true><<<g, b, 0, stream>>>(P, iter[q], delta, rbound, max_iters); \
                               else k_relax<A, M, false><<<g, b, 0, stream>>>(P, iter[q], delta, rbound, max_iters); } while (0)
     if (mode == MODE_LOWER) {
@@ -981,6 +983,7 @@ int Engine::launch_relax(int mode, float rbound) {
         else UFM_LAUNCH(UFM_ALGO_DFM, MODE_RAISE);
     }
 #undef UFM_LAUNCH
+    if (e1) HIPCHK(hipEventRecord(e1, stream));
     ++iter[q];
     return UFM_OK;
 }
@@ -1003,10 +1006,8 @@ int Engine::run_phase(int mode, float rbound, uint32_t *launches, float *kernel_
                     HIPCHK(hipEventCreate(&a)); HIPCHK(hipEventCreate(&b2));
                     ev.push_back(a); ev.push_back(b2);
                 }
-                HIPCHK(hipEventRecord(ev[2 * k], stream));
             }
-            launch_relax(mode, rbound);
-            if (profiling) HIPCHK(hipEventRecord(ev[2 * k + 1], stream));
+            launch_relax(mode, rbound, profiling ? ev[2 * k] : nullptr, profiling ? ev[2 * k + 1] : nullptr);
         }
         HIPCHK(hipGetLastError());
         *launches += (uint32_t)batch;
