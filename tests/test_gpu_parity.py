@@ -290,3 +290,45 @@ def test_first_plan_large(algo, size):
     if algo != "DFM":
         assert nbad == 0
     g.close()
+
+
+def test_patches_accumulate_until_the_next_step():
+    """Several patch_map calls before one step() (overlapping, one of them a no-op) are all
+    propagated -- a superset of the reference, which keeps only the last patch's change list
+    (Graph.cpp:37).  Checked against a fresh plan on the patched raster, full-field mode, bitwise."""
+    width = length = 200
+    cost = ufm_amd.synth.cost_map(77, width, length)
+    start, goal = ufm_amd.synth.start_goal(width, length)
+    g = ufm_amd.Planner(ufm_amd.ALGO_SG, 2)
+    g.set_param("focused", 0)
+    g.set_occupancy_threshold(1); g.set_map(cost); g.set_start(*start); g.set_goal(*goal)
+    assert g.step() == 0
+    cur = cost.copy()
+    rng = np.random.default_rng(5)
+    patches = [(40, 50, rng.integers(1, 200, (20, 30), dtype=np.uint8)),
+               (50, 60, rng.integers(150, 255, (25, 25), dtype=np.uint8)),      # overlaps the first, raises costs
+               (120, 30, None)]                                                  # a no-op patch (current bytes)
+    for (x, y, pt) in patches:
+        if pt is None:
+            pt = cur[x:x + 10, y:y + 10].copy()
+        g.patch_map(pt, x, y)
+        cur[x:x + pt.shape[0], y:y + pt.shape[1]] = pt
+    g.set_start(*start)
+    assert g.step() == 0
+    assert g.num_nodes_updated > 0
+    f = ufm_amd.Planner(ufm_amd.ALGO_SG, 2)
+    f.set_param("focused", 0)
+    f.set_occupancy_threshold(1); f.set_map(cur); f.set_start(*start); f.set_goal(*goal)
+    assert f.step() == 0
+    assert np.array_equal(g.g(), f.g())
+    assert np.array_equal(g.read_map(width, length), cur)
+    # a step without set_start does not propagate a pending patch (ReplannerBase.h:56) ...
+    g.patch_map(np.full((5, 5), 9, np.uint8), 10, 10)
+    before = g.g()
+    assert g.step() == 0
+    assert np.array_equal(before, g.g()) and g.num_nodes_expanded == 0
+    # ... the next one with set_start does
+    g.set_start(*start)
+    assert g.step() == 0
+    assert g.num_nodes_updated > 0
+    g.close(); f.close()
