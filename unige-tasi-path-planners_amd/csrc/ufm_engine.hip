@@ -6,16 +6,17 @@
 // (FieldDStar/FieldDPlanner_impl.h:15-163, ShiftedGridFastMarching/
 // ShiftedGridPlanner_impl.h:9-231, DynamicFastMarching/DynamicFastMarching_impl.h:6-132).
 //
-// How: the serial D*-Lite expansion order is replaced by a block Fast Iterative
-// Method.  The field G lives densely in HBM; the domain is cut into 32x32-element
-// tiles; an active-tile list drives launches of k_relax, which stages one tile
-// (+1 halo) in LDS, sweeps it in place until it stops changing (wave-level
-// ballots keep idle 8x8 patches from re-evaluating), writes it back and
-// activates the neighbours whose halo changed.  The fixed point G = F(G) is
-// unique (costs >= 1), so it equals the reference's consistent field.
-// Map patches (cost increases) are handled by an invalidation ("raise") phase
-// -- an element whose value is no longer supported by its neighbours is reset
-// to +inf, transitively -- followed by the usual lowering phase.
+// How: the serial D*-Lite expansion order is replaced by a block Fast Iterative Method ordered
+// like fast marching at tile granularity.  The field G lives densely in HBM; the domain is cut
+// into UFM_TILE x UFM_TILE-element tiles (16 by default); per-tile priorities (the smallest value
+// that entered a tile since its last visit) drive launches of k_relax, which releases the tiles of
+// the current band, stages each (+1 halo) in LDS, sweeps it to its local fixed point with
+// asynchronous waves (one 4x4-node patch per wave, four lanes per node), writes it back and queues
+// the neighbours whose halo changed.  The fixed point G = F(G) is unique (costs >= 1), so it equals
+// the reference's consistent field.  Map patches (cost increases) are handled by an invalidation
+// ("raise") phase -- an element whose value is no longer supported by its neighbours is reset to
+// +inf, transitively -- followed by the usual lowering phase; both stop at the start's key like the
+// reference's end_condition and keep the rest queued across steps.  DESIGN.md has the full story.
 //
 // Arithmetic contract (bit parity with oracle/ufm_oracle.c): IEEE fp32, one
 // rounding per operation (-ffp-contract=off), correctly rounded sqrt.
@@ -43,7 +44,7 @@ constexpr int CP = T + 2;      // LDS pitch of the cost tile
 constexpr int PT = T / 4;      // 4x4-node patches per tile side
 constexpr int PR = PT / 4;     // patches per wave per side (the 16 waves form a 4x4 grid)
 constexpr int PPW = PR * PR;   // patches per wave: 4 (T = 32) or 1 (T = 16)
-constexpr int NTHR = 1024;     // one element per lane, 16 waves, each owns an 8x8 patch
+constexpr int NTHR = 1024;     // 16 waves; four lanes per node, each wave owns PPW 4x4-node patches
 #ifndef UFM_IDLE_SLEEP
 #define UFM_IDLE_SLEEP 4
 #endif
@@ -841,7 +842,6 @@ struct Engine {
     size_t d_pmask_cap = 0;
     std::vector<MapState> maps;
     std::vector<PatchRect> pending;
-    std::vector<uint64_t> upd_pending;   // per map
     int iter[2] = {0, 0};            // index k of the next relax launch of each queue (never reset: the queues persist)
     bool focused = true;             // stop at the start's key like the reference (end_condition)
     bool dynamic_mode = true;        // long queues: k_triage + cursor hand-out
@@ -932,7 +932,6 @@ int Engine::alloc(int width, int length) {
     k_fill<<<1024, 256, 0, stream>>>(P.Gprev, P.gstride * nmaps, INFINITY);
     HIPCHK(hipGetLastError());
     pending.clear();
-    upd_pending.assign(nmaps, 0);
     for (auto &ms : maps) { ms.have_map = false; ms.initialize_search = true; }
     return UFM_OK;
 }
