@@ -55,6 +55,8 @@ typedef struct ufm_stats {
     uint64_t crit_sweeps;      /* profiling only: sum over launches of the slowest tile's sweep count */
     uint64_t raise_tile_visits; /* tile visits of the invalidation kernel (subset of tile_visits) */
     float raise_kernel_ms;     /* part of kernel_ms spent in the invalidation kernel */
+    uint32_t queued_lower;     /* tiles still queued after the step (parked beyond the start's key): */
+    uint32_t queued_raise;     /*   the counterpart of the reference's priority_queue.size() */
 } ufm_stats;
 
 /* ---- lifetime: `PlannerT<OPT_LVL> planner{}` (e.g. Tests/Planners/FDSTAR/main.cpp:77) ---- */

@@ -38,6 +38,7 @@ for mi in [int(v) for v in a.max_iters.split(",")]:
             p.patch_map(patch, top, left); p.set_start(*s)
             assert p.step() == 0
             for kk in acc: acc[kk] += getattr(p.stats, kk)
+            qmax = max(locals().get("qmax", 0), p.stats.queued_lower + p.stats.queued_raise)
         t2 = time.perf_counter()
     g = p.g()
     if ref is None: ref = g
@@ -45,6 +46,7 @@ for mi in [int(v) for v in a.max_iters.split(",")]:
     print("scale %-6g maxit %3d | plan %7.2f ms visits %7d launches %5d evals/elem %6.1f | %d replans %7.2f ms visits %7d launches %5d (raise %5d) cells %8d | same=%s" % (
         sc, mi, (t1 - t0) * 1e3, s0["tile_visits"], s0["launches"], s0["elem_evals"] / max(1, s0["expanded"]),
         len(script), (t2 - t1) * 1e3, acc["tile_visits"], acc["launches"], acc["raise_launches"], acc["expanded"], same), flush=True)
+    print("      queued after plan: %d lower / %d raise; max queued during replans: %d" % (s0["queued_lower"], s0["queued_raise"], locals().get("qmax", 0)))
     print("      plan: sweeps/visit(max wave) %.1f  evals/visit %.0f kernel_ms %.2f crit_sweeps/launch %.1f | replans: sweeps/visit %.1f evals/visit %.0f kernel_ms %.2f crit_sweeps/launch %.1f" % (
         s0["tile_iters"] / max(1, s0["tile_visits"]), s0["elem_evals"] / max(1, s0["tile_visits"]), s0["kernel_ms"], s0["crit_sweeps"] / max(1, s0["launches"]),
         acc["tile_iters"] / max(1, acc["tile_visits"]), acc["elem_evals"] / max(1, acc["tile_visits"]), acc["kernel_ms"], acc["crit_sweeps"] / max(1, acc["launches"])), flush=True)

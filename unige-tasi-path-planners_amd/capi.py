@@ -38,6 +38,8 @@ class Stats(C.Structure):
         ("crit_sweeps", C.c_uint64),
         ("raise_tile_visits", C.c_uint64),
         ("raise_kernel_ms", C.c_float),
+        ("queued_lower", C.c_uint32),
+        ("queued_raise", C.c_uint32),
     ]
 
     def as_dict(self):

@@ -66,6 +66,7 @@ struct DevCounters {
     int cnt[2][3];              // [queue][ring]: candidate-list lengths (ring of three, see k_relax)
     int rel[2][3];              // [queue][ring]: tiles released (relaxed) by the launch that read the list
     int lmin[2][3];             // [queue][ring]: smallest priority ever queued in the list (float bits)
+    int npark[2];               // [queue]: tiles parked beyond the bound (not re-examined by every launch)
     int nready[2];              // [launch parity]: length of the ready list k_triage built
     int rcursor[2];             // [launch parity]: next ready entry to hand to a workgroup
     int tcount;                 // touched-list length
@@ -89,6 +90,9 @@ struct DevParams {
     int *goal;                  // [nmaps][2]
     int *cand;                  // [2 queues][3][NT] queued tiles (global tile ids), ring of three lists
     int *ready;                 // [NT] tiles released by k_triage for the following relax launch
+    int *park;                  // [2 queues][2][NT] parked tiles (list + scratch for compaction)
+    int *pflag;                 // [2 queues][NT] tile is in the park list
+    int *pprio;                 // [2 queues][NT] its priority (float bits)
     int *queued;                // [2 queues][2][NT] tile is in the candidate list of that launch parity
     int *prio;                  // [2 queues][2][NT] float bits: smallest value that entered the tile since its last visit
     int *start;                 // [nmaps][4] start elements (linear index in the map, -1 unused)
@@ -126,6 +130,15 @@ __device__ __forceinline__ void activate(const DevParams &P, int qz, int lst, in
         const int k = atomicAdd(&P.ctr->cnt[qz][lst], 1);
         P.cand[(qz * 3 + lst) * P.NT + k] = gt;
     }
+}
+// A tile whose priority lies beyond the bound (the start's key for lowering, the invalidation
+// bound for raising) is parked: it leaves the launch-to-launch candidate ring -- carrying hundreds
+// of such entries through every launch cost ~4 us per launch -- and is looked at again by k_unpark
+// when a phase starts (the bound only matters then).  Counterpart of the entries the reference
+// leaves in its priority queue when end_condition() fires.
+__device__ __forceinline__ void park_tile(const DevParams &P, int qz, int gt, int pbits) {
+    atomicMin(&P.pprio[qz * P.NT + gt], pbits);
+    if (atomicExch(&P.pflag[qz * P.NT + gt], 1) == 0) P.park[(size_t)(qz * 2) * P.NT + atomicAdd(&P.ctr->npark[qz], 1)] = gt;
 }
 // D*-Lite end condition as a bound on useful work (FieldDPlanner_impl.h:225-256,
 // ShiftedGridPlanner_impl.h:355-386, DynamicFastMarching_impl.h:315-320): the largest key
@@ -397,8 +410,11 @@ __global__ __launch_bounds__(NTHR) void k_relax(DevParams P, int k, float delta,
             }
             __syncthreads();                               // everyone holds pbits; LDS of the previous tile is free
             if (tid == 0) { queued[gt] = 0; prio[gt] = INFBITS; }
-            if (!release) {                                // not yet: carry over
-                if (tid == 0) activate(P, Q, rn, pn, gt, pbits, !parked);
+            if (!release) {                                // not yet: carry over / park beyond the bound
+                if (tid == 0) {
+                    if (parked || MODE == MODE_RAISE) park_tile(P, Q, gt, pbits);
+                    else activate(P, Q, rn, pn, gt, pbits);
+                }
                 continue;
             }
             if (tid == 0) atomicAdd(&P.ctr->rel[Q][r], 1);
@@ -620,7 +636,8 @@ __global__ void k_triage(DevParams P, int k, float delta, float rbound) {
         queued[gt] = 0;
         prio[gt] = INFBITS;
         if (release) P.ready[atomicAdd(&P.ctr->nready[k & 1], 1)] = gt;
-        else activate(P, Q, rn, pn, gt, pbits, !parked);
+        else if (parked || MODE == MODE_RAISE) park_tile(P, Q, gt, pbits);
+        else activate(P, Q, rn, pn, gt, pbits);
     }
 }
 
@@ -710,6 +727,34 @@ __global__ void k_touched_to_active(DevParams P, int qz, int k) {
 __global__ void k_activate_list(DevParams P, int qz, int k, const int *tiles, int n) {
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) activate(P, qz, k % 3, k & 1, tiles[i], 0);
 }
+// Phase start: parked tiles whose priority is now inside the bound go back to the candidate list
+// of launch k; the others stay parked.  One workgroup.
+__global__ void k_unpark(DevParams P, int qz, int k, float rbound) {
+    __shared__ int s_keep;
+    if (threadIdx.x == 0) s_keep = 0;
+    __syncthreads();
+    const int n = P.ctr->npark[qz];
+    int *list = P.park + (size_t)(qz * 2) * P.NT, *tmp = list + P.NT;
+    const float rb = (rbound < 0.0f) ? P.ctr->rbound : rbound;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        const int gt = list[i];
+        const int pbits = P.pprio[qz * P.NT + gt];
+        const int m = gt / P.NTm, t = gt - m * P.NTm;
+        bool in;
+        if (qz == Q_LOWER) {
+            const float B = P.focused ? start_bound(P, m) : INFINITY;
+            const float hd = P.focused ? tile_heuristic(P, m, t / P.TY, t % P.TY) : 0.0f;
+            in = (__int_as_float(pbits) + hd < B || B == INFINITY);
+        } else {
+            in = !(__int_as_float(pbits) > rb);
+        }
+        if (in) { P.pflag[qz * P.NT + gt] = 0; P.pprio[qz * P.NT + gt] = INFBITS; activate(P, qz, k % 3, k & 1, gt, pbits); }
+        else tmp[atomicAdd(&s_keep, 1)] = gt;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < s_keep; i += blockDim.x) list[i] = tmp[i];
+    if (threadIdx.x == 0) P.ctr->npark[qz] = s_keep;
+}
 // smallest priority waiting in queue qz (list of launch k); one workgroup
 __global__ void k_queue_min(DevParams P, int qz, int k) {
     __shared__ int s_m;
@@ -719,6 +764,10 @@ __global__ void k_queue_min(DevParams P, int qz, int k) {
     int lmin = INFBITS;
     for (int i = threadIdx.x; i < n; i += blockDim.x)
         lmin = min(lmin, P.prio[(size_t)(qz * 2 + (k & 1)) * P.NT + P.cand[(size_t)(qz * 3 + k % 3) * P.NT + i]]);
+    {
+        const int np = P.ctr->npark[qz];
+        for (int i = threadIdx.x; i < np; i += blockDim.x) lmin = min(lmin, P.pprio[qz * P.NT + P.park[(size_t)(qz * 2) * P.NT + i]]);
+    }
     if (lmin != INFBITS) atomicMin(&s_m, lmin);
     __syncthreads();
     if (threadIdx.x == 0) P.ctr->qmin[qz] = s_m;
@@ -755,6 +804,10 @@ __global__ void k_check(DevParams P, int kr, int kl, float margin) {
     int lmin = INFBITS;
     for (int i = threadIdx.x; i < n; i += blockDim.x)
         lmin = min(lmin, P.prio[(size_t)(Q_RAISE * 2 + (kr & 1)) * P.NT + P.cand[(size_t)(Q_RAISE * 3 + kr % 3) * P.NT + i]]);
+    {   // ... and the parked invalidations
+        const int np = P.ctr->npark[Q_RAISE];
+        for (int i = threadIdx.x; i < np; i += blockDim.x) lmin = min(lmin, P.pprio[Q_RAISE * P.NT + P.park[(size_t)(Q_RAISE * 2) * P.NT + i]]);
+    }
     if (lmin != INFBITS) atomicMin(&s_m, lmin);
     __syncthreads();
     if (threadIdx.x) return;
@@ -871,7 +924,7 @@ struct Engine {
 
 void Engine::release() {
     if (!allocated) return;
-    hipFree(P.G); hipFree(P.Gprev); hipFree(P.cost); hipFree(P.goal); hipFree(P.cand); hipFree(P.ready); hipFree(P.queued); hipFree(P.prio); hipFree(P.start); hipFree(P.bnd); hipFree(P.spos);
+    hipFree(P.G); hipFree(P.Gprev); hipFree(P.cost); hipFree(P.goal); hipFree(P.cand); hipFree(P.ready); hipFree(P.park); hipFree(P.pflag); hipFree(P.pprio); hipFree(P.queued); hipFree(P.prio); hipFree(P.start); hipFree(P.bnd); hipFree(P.spos);
     hipFree(P.touched); hipFree(P.tlist); hipFree(P.sflag); hipFree(P.slist); hipFree(P.slist2);
     hipFree(P.mark); hipFree(P.num_updated); hipFree(P.consume); hipFree(P.lmax); hipFree(P.ctr);
     hipFree(d_scratch);
@@ -902,6 +955,9 @@ int Engine::alloc(int width, int length) {
     HIPCHK(hipMalloc(&P.goal, sizeof(int) * 2 * nmaps));
     HIPCHK(hipMalloc(&P.cand, sizeof(int) * 6 * P.NT));
     HIPCHK(hipMalloc(&P.ready, sizeof(int) * P.NT));
+    HIPCHK(hipMalloc(&P.park, sizeof(int) * 4 * P.NT));
+    HIPCHK(hipMalloc(&P.pflag, sizeof(int) * 2 * P.NT));
+    HIPCHK(hipMalloc(&P.pprio, sizeof(int) * 2 * P.NT));
     HIPCHK(hipMalloc(&P.queued, sizeof(int) * 4 * P.NT));
     HIPCHK(hipMalloc(&P.prio, sizeof(int) * 4 * P.NT));
     HIPCHK(hipMalloc(&P.start, sizeof(int) * 4 * nmaps));
@@ -940,7 +996,9 @@ int Engine::alloc(int width, int length) {
 int Engine::reset_queues() {
     HIPCHK(hipMemsetAsync(P.queued, 0, sizeof(int) * 4 * P.NT, stream));
     k_fill<<<64, 256, 0, stream>>>(reinterpret_cast<float *>(P.prio), (size_t)4 * P.NT, INFINITY);
-    HIPCHK(hipMemsetAsync(P.ctr->cnt, 0, sizeof(int) * 22, stream));   // cnt, rel, lmin, nready, rcursor
+    HIPCHK(hipMemsetAsync(P.pflag, 0, sizeof(int) * 2 * P.NT, stream));
+    k_fill<<<64, 256, 0, stream>>>(reinterpret_cast<float *>(P.pprio), (size_t)2 * P.NT, INFINITY);
+    HIPCHK(hipMemsetAsync(P.ctr->cnt, 0, sizeof(int) * 24, stream));   // cnt, rel, lmin, npark, nready, rcursor
     k_fill<<<1, 64, 0, stream>>>(reinterpret_cast<float *>(&P.ctr->lmin[0][0]), (size_t)6, INFINITY);
     last_active = 1;
     iter[0] = iter[1] = 0;
@@ -1148,6 +1206,7 @@ int Engine::step(ufm_stats *out) {
         // short the general adaptive loop below takes over.
         k_seeds_to_active<<<1, 1024, 0, stream>>>(P, Q_RAISE, iter[Q_RAISE]);
         k_prepare_bound<<<1, 64, 0, stream>>>(P, band);
+        k_unpark<<<1, 1024, 0, stream>>>(P, Q_RAISE, iter[Q_RAISE], -1.0f);
         const int nr = hist_raise + 2, nl = hist_lower + 2;
         hipEvent_t e0 = nullptr, e1 = nullptr, e2 = nullptr, e3 = nullptr;
         if (profiling) {
@@ -1159,6 +1218,7 @@ int Engine::step(ufm_stats *out) {
         for (int i = 0; i < nr; ++i) launch_relax(MODE_RAISE, -1.0f);
         if (profiling) HIPCHK(hipEventRecord(e1, stream));
         k_touched_to_active<<<64, 256, 0, stream>>>(P, Q_LOWER, iter[Q_LOWER]);
+        k_unpark<<<1, 1024, 0, stream>>>(P, Q_LOWER, iter[Q_LOWER], INFINITY);
         if (profiling) HIPCHK(hipEventRecord(e2, stream));
         for (int i = 0; i < nl; ++i) launch_relax(MODE_LOWER, INFINITY);
         if (profiling) HIPCHK(hipEventRecord(e3, stream));
@@ -1232,6 +1292,7 @@ int Engine::step(ufm_stats *out) {
             if (do_raise) {
                 uint32_t rl = 0;
                 float rk = 0.0f;
+                k_unpark<<<1, 1024, 0, stream>>>(P, Q_RAISE, iter[Q_RAISE], rbound);
                 int rc = run_phase(MODE_RAISE, rbound, &rl, &rk);
                 if (rc != UFM_OK) return rc;
                 st.kernel_ms += rk; st.raise_kernel_ms += rk;
@@ -1242,6 +1303,7 @@ int Engine::step(ufm_stats *out) {
             }
             const auto tb = std::chrono::steady_clock::now();
             uint32_t ll = 0;
+            k_unpark<<<1, 1024, 0, stream>>>(P, Q_LOWER, iter[Q_LOWER], INFINITY);
             int rc = run_phase(MODE_LOWER, INFINITY, &ll, &st.kernel_ms);
             if (rc != UFM_OK) return rc;
             st.launches += ll;
@@ -1291,6 +1353,8 @@ int Engine::step(ufm_stats *out) {
     }
     for (int m = 0; m < nmaps; ++m) maps[m].new_goal = maps[m].initialize_search = false;
     st.updated = updated;
+    st.queued_lower = (uint32_t)(h_ctr->cnt[Q_LOWER][iter[Q_LOWER] % 3] + h_ctr->npark[Q_LOWER]);   // parked beyond the start's key
+    st.queued_raise = (uint32_t)(h_ctr->cnt[Q_RAISE][iter[Q_RAISE] % 3] + h_ctr->npark[Q_RAISE]);
     st.u_ms = (float)u_acc;   // seeding + invalidation (the reference's update())
     st.p_ms = (float)p_acc;   // propagation + finalisation (the reference's plan())
     last = st;
