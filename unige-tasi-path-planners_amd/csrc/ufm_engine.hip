@@ -1082,7 +1082,7 @@ int Engine::run_phase(int mode, float rbound, uint32_t *launches, float *kernel_
         if (active == 0) return UFM_OK;
         if (h_ctr->rel[q][(iter[q] + 2) % 3] == 0) return UFM_OK;   // the last launch released nothing
         if (total > cap) return UFM_ERR_NOT_CONVERGED;
-        batch = batch_fixed > 0 ? batch_fixed : (active > 256 ? 16 : (active > 32 ? 8 : 4));
+        batch = batch_fixed > 0 ? batch_fixed : (active > 512 ? 32 : (active > 256 ? 16 : (active > 32 ? 8 : 4)));
     }
 }
 
