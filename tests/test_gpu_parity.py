@@ -332,3 +332,38 @@ def test_patches_accumulate_until_the_next_step():
     assert g.step() == 0
     assert g.num_nodes_updated > 0
     g.close(); f.close()
+
+
+def test_headline_size_4096_against_oracle_and_properties():
+    """BASELINE.json's headline configuration (Field D* level 1, 4096x4096): the full plan and a few
+    replans are compared with the oracle bit for bit on the set a planner honouring end_condition
+    must have finalised, plus size-independent properties (idempotence, goal value, a second engine
+    in full-field mode agrees below the start's key)."""
+    size, seed = 4096, 7
+    cost = ufm_amd.synth.cost_map(seed, size, size)
+    start, goal = ufm_amd.synth.start_goal(size, size)
+    o, g = make_pair(ALGOS["FD"], 1, cost, start, goal)
+    u = ufm_amd.Planner(ufm_amd.ALGO_FD, 1)
+    u.set_param("focused", 0)
+    u.set_occupancy_threshold(1); u.set_map(cost); u.set_start(*start); u.set_goal(*goal)
+    assert o.step() == 0 and g.step() == 0 and u.step() == 0
+    n, nbad = check_parity(o, g, "FD-1 4096 plan", below_start_key=True)
+    assert n > 16_000_000 and nbad == 0
+    assert g.g()[int(goal[0]), int(goal[1])] == 0.0
+    for k, s, top, left, patch in ufm_amd.synth.replan_script(seed, size, size, n_patches=4):
+        for p in (o, g, u):
+            p.patch_map(patch, top, left)
+            p.set_start(*s)
+            assert p.step() == 0
+        n, nbad = check_parity(o, g, "FD-1 4096 replan %d" % k, below_start_key=True)
+        assert nbad == 0
+        gf, gu = g.g(), u.g()
+        key = max(gu[int(s[0]) + a, int(s[1]) + b] for a in (0, 1) for b in (0, 1))
+        m = gu < key
+        assert np.array_equal(gf[m], gu[m])
+    # idempotence: nothing pending, nothing changes
+    before = g.g()
+    g.set_start(*s)
+    assert g.step() == 0
+    assert g.num_nodes_expanded == 0 and np.array_equal(before, g.g())
+    g.close(); u.close()
