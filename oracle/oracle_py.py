@@ -51,6 +51,13 @@ def lib():
             getattr(L, n).restype = f
             getattr(L, n).argtypes = [vp]
         L.orc_top_key.argtypes = [vp, C.POINTER(f), C.POINTER(f)]
+        pi, pf = C.POINTER(i), C.POINTER(f)
+        L.orc_extract_path.restype = i
+        L.orc_extract_path.argtypes = [vp, i, i, i, vp, i, vp, i, pi, pf, pf]
+        L.orc_extract_path_field.restype = i
+        L.orc_extract_path_field.argtypes = [vp, i, i, i, vp, i, i, i, f, f, f, f, i, i, i, vp, i, vp, i, pi, pf, pf]
+        L.orc_threshold_uchar.restype = i
+        L.orc_threshold_uchar.argtypes = [vp]
         _LIB = L
     return _LIB
 
@@ -133,6 +140,22 @@ class OraclePlanner:
     def inmap(self):
         return self._arr(self.L.orc_inmap, np.uint8)
 
+    # ---- path extraction on this planner's RHS field ----
+    def extract_path(self, max_steps=20, lookahead=True, allow_indirect=True):
+        """LinearInterpolationPathExtractor::extract_path (PathExtraction impl:11-58):
+        returns (points[n,2], step_costs[m], total_cost, total_dist)."""
+        cap = 3 * max_steps + 1
+        pts = np.zeros((cap, 2), np.float32)
+        costs = np.zeros(2 * max_steps, np.float32)
+        nc, tc, td = C.c_int(), C.c_float(), C.c_float()
+        n = self.L.orc_extract_path(self.h, int(lookahead), int(max_steps), int(allow_indirect),
+                                    pts.ctypes.data, cap, costs.ctypes.data, costs.size,
+                                    C.byref(nc), C.byref(tc), C.byref(td))
+        return pts[:n].copy(), costs[:nc.value].copy(), tc.value, td.value
+
+    def threshold_uchar(self):
+        return self.L.orc_threshold_uchar(self.h)
+
     @property
     def num_expanded(self):
         return self.L.orc_num_expanded(self.h)
@@ -196,3 +219,23 @@ class OraclePlanner:
         if below_start_key:
             m &= k1 < self.start_key()
         return m
+
+
+def extract_path_field(rhs, cells, cost_map, thr_uchar, start, goal, max_steps=20, lookahead=True,
+                       allow_indirect=True):
+    """The oracle's extractor run on an arbitrary dense RHS field (e.g. one read back from the GPU
+    engine): isolates extractor parity from field parity."""
+    L = lib()
+    rhs = np.ascontiguousarray(rhs, np.float32)
+    cost_map = np.ascontiguousarray(cost_map, np.uint8)
+    cap = 3 * max_steps + 1
+    pts = np.zeros((cap, 2), np.float32)
+    costs = np.zeros(2 * max_steps, np.float32)
+    nc, tc, td = C.c_int(), C.c_float(), C.c_float()
+    n = L.orc_extract_path_field(rhs.ctypes.data, rhs.shape[0], rhs.shape[1], int(cells),
+                                 cost_map.ctypes.data, cost_map.shape[1], cost_map.shape[0], int(thr_uchar),
+                                 float(start[0]), float(start[1]), float(goal[0]), float(goal[1]),
+                                 int(lookahead), int(max_steps), int(allow_indirect),
+                                 pts.ctypes.data, cap, costs.ctypes.data, costs.size,
+                                 C.byref(nc), C.byref(tc), C.byref(td))
+    return pts[:n].copy(), costs[:nc.value].copy(), tc.value, td.value

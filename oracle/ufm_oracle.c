@@ -799,3 +799,14 @@ void orc_top_key(const orc_t *p, float *k1, float *k2) {
     if (p->hn > 0) { *k1 = p->hkey[0].k1; *k2 = p->hkey[0].k2; }
     else { *k1 = INFINITY; *k2 = INFINITY; }
 }
+
+/* path extraction on this planner's field (LinearInterpolationPathExtractor reads map.get_interp_rhs
+ * and grid.get_cost / start_pos_ / goal_pos_, PathExtraction impl:76-77, 183, 216, 232-233) */
+int orc_threshold_uchar(const orc_t *p) { return p->thr_uchar; }
+int orc_extract_path(const orc_t *p, int lookahead, int max_steps, int allow_indirect,
+                     float *path_xy, int cap_pts, float *costs, int cap_costs,
+                     int *n_costs, float *total_cost, float *total_dist) {
+    return orc_extract_path_field(p->rhs, p->nx, p->ny, p->algo == ORC_ALGO_DFM, p->map, p->W, p->L, p->thr_uchar,
+                                  p->start_px, p->start_py, p->goal_px, p->goal_py, lookahead, max_steps,
+                                  allow_indirect, path_xy, cap_pts, costs, cap_costs, n_costs, total_cost, total_dist);
+}

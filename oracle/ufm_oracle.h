@@ -62,6 +62,23 @@ float orc_p_time_ms(const orc_t *p);
 /* key at the top of the queue after the last step (inf,inf when empty) */
 void orc_top_key(const orc_t *p, float *k1, float *k2);
 
+/* ---- path extraction (consumer of the RHS field), ufm_path_oracle.c ----------------------
+ * Restatement of LinearInterpolationPathExtractor::extract_path on plain arrays: `rhs` is a
+ * dense row-major [nx][ny] field (cells != 0: cell-centred, as DFM's), `map` the [length][width]
+ * raster.  Returns the number of path points (0: no valid path); points are written as (x,y)
+ * pairs up to cap_pts, step costs up to cap_costs (*n_costs is the full count). */
+int orc_extract_path_field(const float *rhs, int nx, int ny, int cells,
+                           const uint8_t *map, int width, int length, int thr_uchar,
+                           float start_x, float start_y, float goal_x, float goal_y,
+                           int lookahead, int max_steps, int allow_indirect,
+                           float *path_xy, int cap_pts, float *costs, int cap_costs,
+                           int *n_costs, float *total_cost, float *total_dist);
+/* the same on the oracle planner's own RHS field, raster, threshold, start and goal */
+int orc_extract_path(const orc_t *p, int lookahead, int max_steps, int allow_indirect,
+                     float *path_xy, int cap_pts, float *costs, int cap_costs,
+                     int *n_costs, float *total_cost, float *total_dist);
+int orc_threshold_uchar(const orc_t *p);
+
 #ifdef __cplusplus
 }
 #endif

@@ -42,6 +42,32 @@ def test_noise_trap_known_answers(ref_bitmaps, algo, lvl):
     assert abs(float(g[90, 90]) - g_start) < 1e-3 * 11.9
 
 
+# SURVEY.md App. E, same setup: extractor with max_steps = 800 ->
+#   (points, total_cost, total_dist, allow_indirect_traversals as the reference drivers set it)
+SURVEY_KNOWN_PATH = {
+    "DFM": (154, 11808.9, 123.087, True),     # Tests/Planners/DFM/main.cpp:80
+    "SG": (146, 11721.3, 121.725, False),     # Tests/Planners/SGDFM/main.cpp:97
+    "FD": (146, 11721.3, 121.725, True),      # Tests/Planners/FDSTAR/main.cpp:82
+}
+
+
+@pytest.mark.parametrize("algo,lvl", [("FD", 0), ("FD", 1), ("SG", 0), ("SG", 2), ("DFM", 0), ("DFM", 1)])
+def test_noise_trap_path_known_answers(ref_bitmaps, algo, lvl):
+    """Pins the path-extraction restatement (oracle/ufm_path_oracle.c) on the numbers the reference
+    produced for its own bitmap."""
+    cost, sg = ref_bitmaps["noise-trap"]
+    p = _plan(algo, lvl, cost, sg)
+    npts, tcost, tdist, indirect = SURVEY_KNOWN_PATH[algo]
+    pts, costs, total_cost, total_dist = p.extract_path(max_steps=800, allow_indirect=indirect)
+    assert len(pts) == npts
+    assert abs(total_cost - tcost) < 0.06          # known answers are quoted to 6 digits
+    assert abs(total_dist - tdist) < 6e-4
+    assert tuple(pts[0]) == (90.0, 90.0) and tuple(pts[-1]) == (25.0, 25.0)
+    # the reference's wire format assumes one step cost per segment (run_simulator.py:82-83)
+    assert len(costs) == len(pts) - 1
+    assert abs(float(costs.astype(np.float64).sum()) - total_cost) < 1e-2
+
+
 def test_return_codes():
     p = orc.OraclePlanner(orc.ALGO_FD, 0, False)
     assert p.step() == -1          # LOOP_FAILURE_NO_GRAPH, ReplannerBase.h:44
