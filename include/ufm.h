@@ -105,6 +105,25 @@ int ufm_read_map(ufm_t *p, uint8_t *host_map);
  * 0 converges the whole field every step (every element then holds its final value). ---- */
 int ufm_set_param(ufm_t *p, const char *name, double value);
 
+/* ---- path extraction: replaces LinearInterpolationPathExtractor::extract_path
+ * (PathExtraction/LinearInterpolationPathExtractor_impl.h:11-58) and the traversal case tables it
+ * calls (ProjectToolkit/InterpolatedTraversal.cpp).  Walks the RHS field from the start position
+ * (Graph::start_pos_) towards the goal for at most `max_steps` moves (reference default 20);
+ * `lookahead` and `allow_indirect` are the extractor's public members of the same names.
+ * Runs on the device -- the field stays in HBM.  Way points are written as (x,y) pairs, up to
+ * cap_points of them (a move adds <= 3), step costs up to cap_costs (<= 2 per move);
+ * info->n_points / n_costs are the full counts.  n_points == 0: "no valid path exists". ---- */
+typedef struct ufm_path_info {
+    int32_t n_points;      /* path_.size() */
+    int32_t n_costs;       /* cost_.size() */
+    float total_cost;      /* total_cost */
+    float total_dist;      /* total_dist */
+    int32_t steps;         /* moves taken (<= max_steps) */
+    float e_ms;            /* e_time: wall time of the call */
+} ufm_path_info;
+int ufm_extract_path(ufm_t *p, int max_steps, int lookahead, int allow_indirect,
+                     float *path_xy, int cap_points, float *step_costs, int cap_costs, ufm_path_info *info);
+
 /* ---- measurement hooks ---- */
 int ufm_set_profiling(ufm_t *p, int enable);   /* HIP-event timing of every relax launch */
 void *ufm_stream(ufm_t *p);                    /* hipStream_t the kernels run on */
@@ -126,6 +145,9 @@ int ufm_batch_set_goal(ufm_batch_t *b, int i, float x, float y);
 int ufm_batch_reset(ufm_batch_t *b, int i);
 int ufm_batch_step(ufm_batch_t *b, ufm_stats *stats);
 int ufm_batch_read_field(ufm_batch_t *b, int i, int x0, int y0, int nx, int ny, float *g, float *rhs);
+/* all maps in one launch: path_xy [n_maps][cap_points][2], step_costs [n_maps][cap_costs], info [n_maps] */
+int ufm_batch_extract_path(ufm_batch_t *b, int max_steps, int lookahead, int allow_indirect,
+                           float *path_xy, int cap_points, float *step_costs, int cap_costs, ufm_path_info *info);
 
 #ifdef __cplusplus
 }

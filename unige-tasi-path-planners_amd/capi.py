@@ -20,7 +20,7 @@ SYMBOLS = [
     "ufm_version", "ufm_tile_edge", "ufm_batch_create", "ufm_batch_destroy", "ufm_batch_size",
     "ufm_batch_set_occupancy_threshold", "ufm_batch_set_map", "ufm_batch_patch_map",
     "ufm_batch_set_start", "ufm_batch_set_goal", "ufm_batch_reset", "ufm_batch_step",
-    "ufm_batch_read_field",
+    "ufm_batch_read_field", "ufm_extract_path", "ufm_batch_extract_path",
 ]
 
 
@@ -44,6 +44,15 @@ class Stats(C.Structure):
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}
+
+
+class PathInfo(C.Structure):
+    """ufm_path_info (include/ufm.h)"""
+    _fields_ = [
+        ("n_points", C.c_int32), ("n_costs", C.c_int32),
+        ("total_cost", C.c_float), ("total_dist", C.c_float),
+        ("steps", C.c_int32), ("e_ms", C.c_float),
+    ]
 
 
 def library_path():
@@ -97,6 +106,8 @@ def load_library():
     L.ufm_batch_reset.argtypes = [vp, i]
     L.ufm_batch_step.argtypes = [vp, C.POINTER(Stats)]
     L.ufm_batch_read_field.argtypes = [vp, i, i, i, i, i, vp, vp]
+    L.ufm_extract_path.argtypes = [vp, i, i, i, vp, i, vp, i, C.POINTER(PathInfo)]
+    L.ufm_batch_extract_path.argtypes = [vp, i, i, i, vp, i, vp, i, C.POINTER(PathInfo)]
     _LIB = L
     return L
 
@@ -200,6 +211,20 @@ class Planner:
     def g(self):
         return self.read_field()[0]
 
+    def extract_path(self, max_steps=20, lookahead=True, allow_indirect=True):
+        """LinearInterpolationPathExtractor::extract_path on the device:
+        returns (points[n,2], step_costs[m], total_cost, total_dist); the call's info is kept in
+        self.path_info."""
+        cap_p, cap_c = 3 * max_steps + 1, 2 * max_steps
+        pts = np.zeros((cap_p, 2), np.float32)
+        costs = np.zeros(cap_c, np.float32)
+        self.path_info = PathInfo()
+        _chk(self.L.ufm_extract_path(self.h, int(max_steps), int(lookahead), int(allow_indirect),
+                                     pts.ctypes.data, cap_p, costs.ctypes.data, cap_c,
+                                     C.byref(self.path_info)), "ufm_extract_path")
+        pi = self.path_info
+        return pts[:pi.n_points].copy(), costs[:pi.n_costs].copy(), pi.total_cost, pi.total_dist
+
     def read_map(self, width, length):
         m = np.empty((length, width), dtype=np.uint8)
         _chk(self.L.ufm_read_map(self.h, m.ctypes.data), "ufm_read_map")
@@ -258,6 +283,20 @@ class BatchPlanner:
             return rc
         _chk(rc, "ufm_batch_step")
         return rc
+
+    def extract_paths(self, max_steps=20, lookahead=True, allow_indirect=True):
+        """One launch for all maps: list of (points, step_costs, total_cost, total_dist)."""
+        n = self.L.ufm_batch_size(self.h)
+        cap_p, cap_c = 3 * max_steps + 1, 2 * max_steps
+        pts = np.zeros((n, cap_p, 2), np.float32)
+        costs = np.zeros((n, cap_c), np.float32)
+        info = (PathInfo * n)()
+        _chk(self.L.ufm_batch_extract_path(self.h, int(max_steps), int(lookahead), int(allow_indirect),
+                                           pts.ctypes.data, cap_p, costs.ctypes.data, cap_c, info),
+             "ufm_batch_extract_path")
+        self.path_info = info
+        return [(pts[k, :info[k].n_points].copy(), costs[k, :info[k].n_costs].copy(),
+                 info[k].total_cost, info[k].total_dist) for k in range(n)]
 
     def read_field(self, i):
         nx, ny = self._dims

@@ -865,6 +865,8 @@ __global__ __launch_bounds__(T * T) void k_finalize(DevParams P, int only_if_don
 
 struct PatchRect { int m, x, y, w, h; };
 
+#include "ufm_path.h"
+
 struct MapState {
     bool initialize_search = true;   // ReplannerBase.h:149
     bool goal_set = false;           // :150
@@ -893,6 +895,9 @@ struct Engine {
     uint8_t *h_patch = nullptr;      // pinned staging
     uint8_t *d_pmask = nullptr;      // changed-cell mask of the patch being applied
     size_t d_pmask_cap = 0;
+    PathJob *d_jobs = nullptr, *h_jobs = nullptr;     // path extraction: per-map start / goal (h_: pinned)
+    float *d_path = nullptr, *h_path = nullptr;       // per-map output records
+    size_t path_cap = 0;                              // floats per buffer
     std::vector<MapState> maps;
     std::vector<PatchRect> pending;
     int iter[2] = {0, 0};            // index k of the next relax launch of each queue (never reset: the queues persist)
@@ -1392,6 +1397,10 @@ int engine_destroy(Engine *e) {
     for (hipEvent_t v : e->ev) hipEventDestroy(v);
     if (e->d_patch) hipFree(e->d_patch);
     if (e->d_pmask) hipFree(e->d_pmask);
+    if (e->d_jobs) hipFree(e->d_jobs);
+    if (e->h_jobs) hipHostFree(e->h_jobs);
+    if (e->d_path) hipFree(e->d_path);
+    if (e->h_path) hipHostFree(e->h_path);
     if (e->h_patch) hipHostFree(e->h_patch);
     if (e->h_ctr) hipHostFree(e->h_ctr);
     if (e->h_scratch) hipHostFree(e->h_scratch);
@@ -1472,6 +1481,60 @@ int engine_read_field(Engine *e, int m, int x0, int y0, int nx, int ny, float *g
     HIPCHK(hipStreamSynchronize(e->stream));
     // at the fixed point RHS(s) = F(G)(s) = G(s) for every element (goal: 0 = 0)
     if (g && rhs) std::memcpy(rhs, g, (size_t)nx * ny * sizeof(float));
+    return UFM_OK;
+}
+
+// Path extraction for all maps of the engine in one launch (one wavefront per map).
+// path_xy: [nmaps][cap_pts][2], step_costs: [nmaps][cap_costs], info: [nmaps].
+int engine_extract_path(Engine *e, int max_steps, int lookahead, int allow_indirect,
+                        float *path_xy, int cap_pts, float *step_costs, int cap_costs, ufm_path_info *info) {
+    if (!e || !e->allocated || !info || max_steps < 1 || cap_pts < 0 || cap_costs < 0) return UFM_ERR_INVALID;
+    if ((cap_pts > 0 && !path_xy) || (cap_costs > 0 && !step_costs)) return UFM_ERR_INVALID;
+    for (const MapState &ms : e->maps) if (!ms.have_map || !ms.start_set || !ms.goal_set) return UFM_ERR_INVALID;
+    HIPCHK(hipSetDevice(e->device));
+    const auto t0 = std::chrono::steady_clock::now();
+    const int n = e->nmaps;
+    // the device keeps what the caller has room for, at most what max_steps moves can produce
+    const int dev_pts = std::min(cap_pts, 3 * max_steps + 1), dev_cst = std::min(cap_costs, 2 * max_steps);
+    const size_t ostride = PATH_HDR + 2 * (size_t)dev_pts + dev_cst;
+    if (ostride * n > e->path_cap) {
+        HIPCHK(hipStreamSynchronize(e->stream));
+        if (e->d_path) hipFree(e->d_path);
+        if (e->h_path) hipHostFree(e->h_path);
+        e->d_path = nullptr; e->h_path = nullptr; e->path_cap = 0;
+        HIPCHK(hipMalloc(&e->d_path, ostride * n * sizeof(float)));
+        HIPCHK(hipHostMalloc(&e->h_path, ostride * n * sizeof(float)));
+        e->path_cap = ostride * n;
+    }
+    if (!e->d_jobs) {
+        HIPCHK(hipMalloc(&e->d_jobs, sizeof(PathJob) * n));
+        HIPCHK(hipHostMalloc(&e->h_jobs, sizeof(PathJob) * n));
+    }
+    for (int m = 0; m < n; ++m) e->h_jobs[m] = PathJob{e->maps[m].start_x, e->maps[m].start_y, e->maps[m].goal_x, e->maps[m].goal_y};
+    HIPCHK(hipMemcpyAsync(e->d_jobs, e->h_jobs, sizeof(PathJob) * n, hipMemcpyHostToDevice, e->stream));
+    PathField F{};
+    F.G = e->P.G; F.cost = e->P.cost;
+    F.EX = e->P.EX; F.EY = e->P.EY; F.L = e->P.L; F.W = e->P.W; F.pitch = e->P.pitch; F.thr = e->P.thr;
+    F.cells = (e->algo == UFM_ALGO_DFM); F.indirect = allow_indirect != 0;
+    k_extract_path<<<n, 64, 0, e->stream>>>(F, e->P.gstride, e->P.cstride, e->d_jobs, e->d_path, ostride,
+                                            dev_pts, dev_cst, lookahead != 0, max_steps);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(e->h_path, e->d_path, ostride * n * sizeof(float), hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    for (int m = 0; m < n; ++m) {
+        const float *o = e->h_path + ostride * m;
+        ufm_path_info &pi = info[m];
+        std::memcpy(&pi.n_points, &o[0], 4);
+        std::memcpy(&pi.n_costs, &o[1], 4);
+        pi.total_cost = o[2];
+        pi.total_dist = o[3];
+        std::memcpy(&pi.steps, &o[4], 4);
+        const int np = std::min(pi.n_points, dev_pts), nc = std::min(pi.n_costs, dev_cst);
+        if (np > 0) std::memcpy(path_xy + (size_t)m * cap_pts * 2, o + PATH_HDR, sizeof(float) * 2 * np);
+        if (nc > 0) std::memcpy(step_costs + (size_t)m * cap_costs, o + PATH_HDR + 2 * (size_t)dev_pts, sizeof(float) * nc);
+    }
+    const float ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    for (int m = 0; m < n; ++m) info[m].e_ms = ms;
     return UFM_OK;
 }
 
@@ -1595,5 +1658,14 @@ int ufm_batch_step(ufm_batch_t *b, ufm_stats *stats) {
     return b->e->step(stats);
 }
 int ufm_batch_read_field(ufm_batch_t *b, int i, int x0, int y0, int nx, int ny, float *g, float *rhs) { return b ? engine_read_field(b->e, i, x0, y0, nx, ny, g, rhs) : UFM_ERR_INVALID; }
+
+int ufm_extract_path(ufm_t *p, int max_steps, int lookahead, int allow_indirect,
+                     float *path_xy, int cap_points, float *step_costs, int cap_costs, ufm_path_info *info) {
+    return p ? engine_extract_path(p->e, max_steps, lookahead, allow_indirect, path_xy, cap_points, step_costs, cap_costs, info) : UFM_ERR_INVALID;
+}
+int ufm_batch_extract_path(ufm_batch_t *b, int max_steps, int lookahead, int allow_indirect,
+                           float *path_xy, int cap_points, float *step_costs, int cap_costs, ufm_path_info *info) {
+    return b ? engine_extract_path(b->e, max_steps, lookahead, allow_indirect, path_xy, cap_points, step_costs, cap_costs, info) : UFM_ERR_INVALID;
+}
 
 }  // extern "C"
