@@ -76,6 +76,7 @@ class ExpandedMap {
 
   // ---- wiring (used by ReplannerBase) ----
   void attach(ufm_t *h) { handle_ = h; }
+  ufm_t *native_handle() const { return handle_; }
   void set_dims(int nx, int ny) { nx_ = nx; ny_ = ny; invalidate(); }
   void invalidate() const { cache_.clear(); }
   void clear() noexcept { invalidate(); buckets.clear(); }
