@@ -13,6 +13,7 @@ ap.add_argument("--scales", default="0.25,0.5,1,2,4,1e9")
 ap.add_argument("--max-iters", default="128")
 ap.add_argument("--reps", type=int, default=2)
 ap.add_argument("--profile", type=int, default=0)
+ap.add_argument("--param", action="append", default=[], help="name=value for ufm_set_param")
 a = ap.parse_args()
 algo = {"FD": 0, "SG": 1, "DFM": 2}[a.algo]
 size, seed = a.size, 7
@@ -22,6 +23,9 @@ script = list(ufm_amd.synth.replan_script(seed, size, size, n_patches=a.patches)
 p = ufm_amd.Planner(algo, 1 if algo != 1 else 2)
 p.set_occupancy_threshold(1)
 p.set_profiling(a.profile)
+for kv in a.param:
+    name, val = kv.split("=")
+    p.set_param(name, float(val))
 ref = None
 for mi in [int(v) for v in a.max_iters.split(",")]:
   for sc in [float(v) for v in a.scales.split(",")]:

@@ -45,6 +45,15 @@ constexpr int PT = T / 4;      // 4x4-node patches per tile side
 constexpr int PR = PT / 4;     // patches per wave per side (the 16 waves form a 4x4 grid)
 constexpr int PPW = PR * PR;   // patches per wave: 4 (T = 32) or 1 (T = 16)
 constexpr int NTHR = 1024;     // 16 waves; four lanes per node, each wave owns PPW 4x4-node patches
+#ifndef UFM_CAUSAL_FILTER
+#define UFM_CAUSAL_FILTER 1    // do not wake a neighbour tile that a changed border value cannot influence
+#endif
+#ifndef UFM_LPT
+#define UFM_LPT 1              // longest-expected-first hand-out of the ready list
+#endif
+#ifndef UFM_LONG_SWEEPS
+#define UFM_LONG_SWEEPS 12     // a visit that took at least this many sweeps per wave counts as long
+#endif
 #ifndef UFM_IDLE_SLEEP
 #define UFM_IDLE_SLEEP 4
 #endif
@@ -67,8 +76,13 @@ struct DevCounters {
     int rel[2][3];              // [queue][ring]: tiles released (relaxed) by the launch that read the list
     int lmin[2][3];             // [queue][ring]: smallest priority ever queued in the list (float bits)
     int npark[2];               // [queue]: tiles parked beyond the bound (not re-examined by every launch)
-    int nready[2];              // [launch parity]: length of the ready list k_triage built
+    int nready[2];              // [launch parity]: ready list k_triage built: entries expected to take long (front of the array)
     int rcursor[2];             // [launch parity]: next ready entry to hand to a workgroup
+    int nshort[2];              // [launch parity]: ready entries expected to be short (filled from the back of the array)
+    int last_work[2];           // [queue]: index of the last launch that released a tile (sizes the replan batches)
+    int fin_blocks;             // k_replan_end: workgroups that have finished (the last one publishes)
+    int kbase[2];               // [queue]: launch index at the start of a replan graph (its kernels carry offsets)
+    unsigned int pubseq;        // sequence number the replan graph publishes with
     int tcount;                 // touched-list length
     int scount;                 // pending-seed-list length (survives steps)
     unsigned long long expanded;
@@ -90,6 +104,7 @@ struct DevParams {
     int *goal;                  // [nmaps][2]
     int *cand;                  // [2 queues][3][NT] queued tiles (global tile ids), ring of three lists
     int *ready;                 // [NT] tiles released by k_triage for the following relax launch
+    int *hint;                  // [NT] sweeps the tile's last visit took (longest-first hand-out)
     int *park;                  // [2 queues][2][NT] parked tiles (list + scratch for compaction)
     int *pflag;                 // [2 queues][NT] tile is in the park list
     int *pprio;                 // [2 queues][NT] its priority (float bits)
@@ -120,6 +135,11 @@ struct DevParams {
     size_t mstride;             // bytes per map in mark
 };
 
+// Launch index: a kernel launched directly carries it; a kernel inside the captured replan graph
+// carries -1 - offset and adds the base k_replan_begin_job stored (the graph is replayed unchanged).
+__device__ __forceinline__ int launch_index(const DevParams &P, int qz, int k_arg) {
+    return k_arg >= 0 ? k_arg : P.ctr->kbase[qz] + (-1 - k_arg);
+}
 // queue tile gt in queue qz for the launch that reads list `lst` / priority parity `par`
 // (`banded` = false for an entry that is only parked beyond the start's key: it must not hold the
 // ordering band of the other entries -- of other maps in a batch -- down)
@@ -166,6 +186,31 @@ __device__ __forceinline__ float tile_heuristic(const DevParams &P, int m, int t
     const float dx = fmaxf(fmaxf(x0 - sx, sx - x1), 0.0f), dy = fmaxf(fmaxf(y0 - sy, sy - y1), 0.0f);
     return P.hm * hypotf(dx, dy) * 0.999f;   // (0.999: stay below the reference's own float rounding of the distance)
 }
+
+// ---- optional in-kernel timing of tile visits (-DUFM_TIMING, diagnostic builds only) -------
+// g_tdiag: [0] sum of pop->staged, [1] sum of sweep phases, [2] sum of write-back/activation,
+// [3] visits, [4] sum of per-block busy time, [5] blocks, [8..39] histogram of visit times (2 us bins)
+// all in 10 ns ticks of the constant 100 MHz counter
+#ifdef UFM_TIMING
+__device__ unsigned long long g_tdiag[64];
+// trace of the lowering launches UFM_TRACE_K0 .. +7: per record {launch | block<<16 | kind<<40, t0, t1, sweeps};
+// kind 0 = tile visit (pop .. end), 1 = block lifetime (entry .. exit)
+#ifndef UFM_TRACE_K0
+#define UFM_TRACE_K0 300
+#endif
+__device__ unsigned long long g_trace[4 * 16384];
+__device__ unsigned int g_ntrace;
+__device__ __forceinline__ void trace_rec(int k, int kind, unsigned long long t0, unsigned long long t1, long long sw) {
+    if (k < UFM_TRACE_K0 || k >= UFM_TRACE_K0 + 8) return;
+    const unsigned int i = atomicAdd(&g_ntrace, 1u);
+    if (i >= 16384) return;
+    g_trace[4 * i] = (unsigned long long)k | ((unsigned long long)blockIdx.x << 16) | ((unsigned long long)kind << 40);
+    g_trace[4 * i + 1] = t0; g_trace[4 * i + 2] = t1; g_trace[4 * i + 3] = (unsigned long long)sw;
+}
+#define UFM_TICK(v) const unsigned long long v = wall_clock64()
+#else
+#define UFM_TICK(v)
+#endif
 
 // ---- update operators -------------------------------------------------------
 // Correctly rounded fp32 square root (std::sqrt of the reference, Macros.h:12):
@@ -328,7 +373,7 @@ __device__ __forceinline__ float cell_cost(const DevParams &P, const uint8_t *cm
 // DYN: the tiles come from the ready list k_triage built (taken through an atomic cursor: perfect
 // balance, used while the queue is long); !DYN: triage fused as described above (short queues).
 template <int ALGO, int MODE, bool DYN>
-__global__ __launch_bounds__(NTHR) void k_relax(DevParams P, int k, float delta, float rbound, int max_sweeps) {
+__global__ __launch_bounds__(NTHR) void k_relax(DevParams P, int k_arg, float delta, float rbound, int max_sweeps) {
     __shared__ float Gs[(T + 2) * GP];
     __shared__ float Cs[(T + 1) * CP];
     __shared__ int s_wake[16];  // per wave: bit j = patch j of the wave has new inputs (PPW bits)
@@ -345,14 +390,17 @@ __global__ __launch_bounds__(NTHR) void k_relax(DevParams P, int k, float delta,
     const int io_r = tid / T, io_c = tid % T;                  // HBM mapping (threads tid < T*T)
     const bool io_on = tid < T * T;
     constexpr int Q = (MODE == MODE_LOWER) ? Q_LOWER : Q_RAISE;
+    const int k = launch_index(P, Q, k_arg);
     const int r = k % 3, rn = (k + 1) % 3, rz = (k + 2) % 3, pc = k & 1, pn = pc ^ 1;
-    const int n = DYN ? P.ctr->nready[k & 1] : P.ctr->cnt[Q][r];
+    const int n_long = DYN ? P.ctr->nready[k & 1] : 0;
+    const int n = DYN ? n_long + P.ctr->nshort[k & 1] : P.ctr->cnt[Q][r];
     if (blockIdx.x == 0 && tid == 0) {
         P.ctr->cnt[Q][rz] = 0; P.ctr->rel[Q][rz] = 0; P.ctr->lmin[Q][rz] = INFBITS;
-        P.ctr->nready[(k + 1) & 1] = 0; P.ctr->rcursor[(k + 1) & 1] = 0;   // for the next triage
-        if (DYN) P.ctr->rel[Q][r] = n;
+        P.ctr->nready[(k + 1) & 1] = 0; P.ctr->nshort[(k + 1) & 1] = 0; P.ctr->rcursor[(k + 1) & 1] = 0;   // for the next triage
+        if (DYN) { P.ctr->rel[Q][r] = n; if (n) P.ctr->last_work[Q] = k; }
     }
     if (n == 0) return;
+    UFM_TICK(tkb);
     const int *cand = P.cand + (size_t)(Q * 3 + r) * P.NT;
     int *prio = P.prio + (size_t)(Q * 2 + pc) * P.NT;
     int *queued = P.queued + (size_t)(Q * 2 + pc) * P.NT;
@@ -392,8 +440,14 @@ __global__ __launch_bounds__(NTHR) void k_relax(DevParams P, int k, float delta,
             __syncthreads();
             i = s_min;
         }
-        if (i >= n) break;
-        const int gt = DYN ? P.ready[i] : cand[i];
+        if (i >= n) {
+#ifdef UFM_TIMING
+            if (MODE == MODE_LOWER && tid == 0) trace_rec(k, 1, tkb, wall_clock64(), 0);
+#endif
+            break;
+        }
+        UFM_TICK(tk0);
+        const int gt = DYN ? (i < n_long ? P.ready[i] : P.ready[P.NT - 1 - (i - n_long)]) : cand[i];
         const int pbits = DYN ? 0 : prio[gt];
         const int m = gt / P.NTm, t = gt - m * P.NTm;
         // lowering: release within the ordering band and below the start's key (end condition);
@@ -417,7 +471,7 @@ __global__ __launch_bounds__(NTHR) void k_relax(DevParams P, int k, float delta,
                 }
                 continue;
             }
-            if (tid == 0) atomicAdd(&P.ctr->rel[Q][r], 1);
+            if (tid == 0) { atomicAdd(&P.ctr->rel[Q][r], 1); atomicMax(&P.ctr->last_work[Q], k); }
         }
         const int tx = t / P.TY, ty = t - tx * P.TY;
         const int x0 = tx * T, y0 = ty * T;
@@ -455,6 +509,11 @@ __global__ __launch_bounds__(NTHR) void k_relax(DevParams P, int k, float delta,
             Cs[cr * CP + cc] = cell_cost(P, cm, x0 + cr - COFF, y0 + cc - COFF);
         }
         __syncthreads();
+        UFM_TICK(tk1);
+#ifdef UFM_TIMING
+        const int dbg_hint = P.hint[gt];
+        const int dbg_ninf0 = __syncthreads_count(io_on && gl0 == INFINITY);
+#endif
         if (s_misc[0] && io_on) P.Gprev[(size_t)m * P.gstride + gidx] = gl0;
 
         // per-lane constants of the wave's four patches
@@ -565,6 +624,7 @@ __global__ __launch_bounds__(NTHR) void k_relax(DevParams P, int k, float delta,
         }
         if (lane == 0 && tot) { atomicAdd(&s_misc[2], tot); atomicMax(&s_misc[3], tot); }
         __syncthreads();
+        UFM_TICK(tk2);
 
         // write back what changed; note which neighbours saw their halo change
         const float gf = io_on ? Gs[(io_r + 1) * GP + io_c + 1] : gl0;
@@ -585,17 +645,43 @@ __global__ __launch_bounds__(NTHR) void k_relax(DevParams P, int k, float delta,
             const int pb = __float_as_int((MODE == MODE_LOWER) ? gf : gl0);
             const int er = (io_r == 0) ? -1 : ((io_r == T - 1) ? 1 : 0);
             const int ec = (io_c == 0) ? -1 : ((io_c == T - 1) ? 1 : 0);
+            // Causality: every value the update operators produce is larger than each input it
+            // depends on (the interpolated cost-to-goal of the far edge plus a positive traversal
+            // cost), so an element h of a neighbour tile can neither be lowered by nor have been
+            // supported by a border value that is, before and after this visit, not below h: the
+            // wake-up -- half of all tile visits used to find nothing to do -- is skipped.  h is read
+            // from the halo as staged.  A neighbour that is being visited in this same launch only
+            // lowers its border meanwhile, which keeps the test conservative -- except for the
+            // ulp-level rises of replace semantics: a tile whose own border ROSE during a visit
+            // therefore comes back once more (s_bmin[4]) and re-reads its neighbours' borders.
+            bool need_r = true, need_c = true, need_d = true;
+            if (UFM_CAUSAL_FILTER && MODE == MODE_LOWER) {
+                const float lo = fminf(gf, gl0);
+                const int cl = max(io_c - 1, 0) + 1, ch = min(io_c + 1, T - 1) + 1;     // halo columns / rows that belong
+                const int rl = max(io_r - 1, 0) + 1, rh = min(io_r + 1, T - 1) + 1;     // to the edge neighbour itself
+                if (er) {
+                    const float *h = Gs + (io_r + 1 + er) * GP;
+                    need_r = lo < fmaxf(fmaxf(h[cl], h[io_c + 1]), h[ch]);
+                }
+                if (ec) {
+                    const int hc = io_c + 1 + ec;
+                    need_c = lo < fmaxf(fmaxf(Gs[rl * GP + hc], Gs[(io_r + 1) * GP + hc]), Gs[rh * GP + hc]);
+                }
+                if (er && ec) need_d = lo < Gs[(io_r + 1 + er) * GP + io_c + 1 + ec];
+                if ((er || ec) && significant && gf > gl0) atomicMin(&s_bmin[4], __float_as_int(gl0));
+            }
             if (!conv) atomicMin(&s_bmin[4], pb);
-            if (er && significant) atomicMin(&s_bmin[(er + 1) * 3 + 1], pb);
-            if (ec && significant) atomicMin(&s_bmin[3 + ec + 1], pb);
-            if (er && ec && significant) atomicMin(&s_bmin[(er + 1) * 3 + ec + 1], pb);
+            if (er && significant && need_r) atomicMin(&s_bmin[(er + 1) * 3 + 1], pb);
+            if (ec && significant && need_c) atomicMin(&s_bmin[3 + ec + 1], pb);
+            if (er && ec && significant && need_d) atomicMin(&s_bmin[(er + 1) * 3 + ec + 1], pb);
         }
         __syncthreads();
         if (tid < 9) {
             const int dr = tid / 3 - 1, dc = tid % 3 - 1;
             if (tid == 4) {
-                if (!conv) activate(P, Q, rn, pn, gt, min(s_bmin[4], INFBITS - 1));   // sweep cap hit: come back
+                if (!conv || s_bmin[4] != INFBITS) activate(P, Q, rn, pn, gt, min(s_bmin[4], INFBITS - 1));   // sweep cap hit / border rose: come back
                 atomicMax(&P.lmax[k & (LMAX - 1)], s_misc[3]);
+                P.hint[gt] = s_misc[3];
                 atomicAdd(&P.ctr->tile_visits, 1ull);
                 if (MODE == MODE_RAISE) atomicAdd(&P.ctr->raise_visits, 1ull);
                 atomicAdd(&P.ctr->tile_iters, (unsigned long long)s_misc[3]);
@@ -605,6 +691,20 @@ __global__ __launch_bounds__(NTHR) void k_relax(DevParams P, int k, float delta,
                 if (ntx >= 0 && ntx < P.TX && nty >= 0 && nty < P.TY) activate(P, Q, rn, pn, m * P.NTm + ntx * P.TY + nty, s_bmin[tid]);
             }
         }
+#ifdef UFM_TIMING
+        if (MODE == MODE_LOWER) {
+            const int dbg_ninf1 = __syncthreads_count(io_on && gf == INFINITY);
+            if (tid == 0) {
+                const unsigned long long tk3 = wall_clock64();
+                atomicAdd(&g_tdiag[0], tk1 - tk0); atomicAdd(&g_tdiag[1], tk2 - tk1); atomicAdd(&g_tdiag[2], tk3 - tk2);
+                atomicAdd(&g_tdiag[3], 1ull);
+                const unsigned long long bin = (tk3 - tk0) / 200;
+                atomicAdd(&g_tdiag[8 + (bin < 31 ? bin : 31)], 1ull);
+                atomicAdd(&g_tdiag[40 + (s_misc[3] < 23 ? s_misc[3] : 23)], 1ull);   // histogram of per-wave sweep counts / 1
+                trace_rec(k, 0, tk0, tk3, (long long)(s_misc[3] & 255) | ((long long)min(s_misc[1], 255) << 8) | ((long long)min(dbg_hint, 255) << 16) | ((long long)dbg_ninf0 << 24) | ((long long)dbg_ninf1 << 40));
+            }
+        }
+#endif
     }
 }
 
@@ -635,7 +735,13 @@ __global__ void k_triage(DevParams P, int k, float delta, float rbound) {
         }
         queued[gt] = 0;
         prio[gt] = INFBITS;
-        if (release) P.ready[atomicAdd(&P.ctr->nready[k & 1], 1)] = gt;
+        if (release) {
+            // a launch lasts (work per CU) + (its longest visit) when long visits are handed out last;
+            // tiles a front is still crossing (first visit of the step, or many sweeps last time) go first
+            const bool lng = UFM_LPT && (P.touched[gt] == 0 || P.hint[gt] >= UFM_LONG_SWEEPS);
+            if (lng) P.ready[atomicAdd(&P.ctr->nready[k & 1], 1)] = gt;
+            else P.ready[P.NT - 1 - atomicAdd(&P.ctr->nshort[k & 1], 1)] = gt;
+        }
         else if (parked || MODE == MODE_RAISE) park_tile(P, Q, gt, pbits);
         else activate(P, Q, rn, pn, gt, pbits);
     }
@@ -648,8 +754,7 @@ __global__ void k_fill(float *p, size_t n, float v) {
 
 // Graph::update (Graph.cpp:36-51) on the device: overwrite the rectangle, remember which cells
 // changed (one byte per patch cell in `pmask`).
-__global__ void k_patch_apply(DevParams P, int m, const uint8_t *patch, uint8_t *pmask, int x, int y, int w, int h) {
-    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+__device__ __forceinline__ void patch_apply(const DevParams &P, int m, const uint8_t *patch, uint8_t *pmask, int x, int y, int w, int h, int e) {
     if (e >= w * h) return;
     const int i = e / w, j = e - i * w;
     uint8_t *cm = P.cost + (size_t)m * P.cstride;
@@ -659,14 +764,16 @@ __global__ void k_patch_apply(DevParams P, int m, const uint8_t *patch, uint8_t 
     pmask[e] = ch;
     if (ch) cm[ci] = nv;
 }
+__global__ void k_patch_apply(DevParams P, int m, const uint8_t *patch, uint8_t *pmask, int x, int y, int w, int h) {
+    patch_apply(P, m, patch, pmask, x, y, w, h, blockIdx.x * blockDim.x + threadIdx.x);
+}
 // Seeding of update(): the corner nodes of the changed cells (FD impl:127-136, Cell.cpp:48-60) or
 // the changed cells themselves (DFM impl:106-112).  One thread per element of the patch's
 // element rectangle, so every element has one owner: plain byte marks, no atomics per element;
 // the counter and the tile seeds are aggregated per wave.
-template <bool NODES>
-__global__ void k_patch_seed(DevParams P, int m, const uint8_t *pmask, int x, int y, int w, int h) {
+template <bool NODES>   // every lane of a wave must call (ballots)
+__device__ __forceinline__ void patch_seed(const DevParams &P, int m, const uint8_t *pmask, int x, int y, int w, int h, int e) {
     const int ew = NODES ? w + 1 : w, eh = NODES ? h + 1 : h;
-    const int e = blockIdx.x * blockDim.x + threadIdx.x;
     bool hit = false;
     int gt = -1;
     if (e < ew * eh) {
@@ -697,17 +804,32 @@ __global__ void k_patch_seed(DevParams P, int m, const uint8_t *pmask, int x, in
         todo &= ~__ballot(gt == t);
     }
 }
-__global__ void k_clear_marks(DevParams P, int m, int x, int y, int w, int h) {
-    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+template <bool NODES>
+__global__ void k_patch_seed(DevParams P, int m, const uint8_t *pmask, int x, int y, int w, int h) {
+    patch_seed<NODES>(P, m, pmask, x, y, w, h, blockIdx.x * blockDim.x + threadIdx.x);
+}
+// a patch of at most 64 x 64 cells: Graph::update and the seeding of update() in one workgroup
+// (each separate launch costs ~5 us of dispatch latency)
+template <bool NODES>
+__global__ __launch_bounds__(1024) void k_patch_small(DevParams P, int m, const uint8_t *patch, uint8_t *pmask, int x, int y, int w, int h) {
+    for (int e = threadIdx.x; e < w * h; e += blockDim.x) patch_apply(P, m, patch, pmask, x, y, w, h, e);
+    __syncthreads();
+    const int ne = NODES ? (w + 1) * (h + 1) : w * h;
+    for (int base = 0; base < ne; base += blockDim.x) patch_seed<NODES>(P, m, pmask, x, y, w, h, base + threadIdx.x);
+}
+__device__ __forceinline__ void clear_mark(const DevParams &P, int m, int x, int y, int w, int h, int e) {
     const int r = e / (w + 1), c = e - r * (w + 1);
     if (r > h) return;
     const int ex = x + r, ey = y + c;
     if (ex >= P.EX || ey >= P.EY) return;
     P.mark[(size_t)m * P.mstride + (size_t)ex * P.EY + ey] = 0;
 }
+__global__ void k_clear_marks(DevParams P, int m, int x, int y, int w, int h) {
+    clear_mark(P, m, x, y, w, h, blockIdx.x * blockDim.x + threadIdx.x);
+}
 // pending seeds of consuming maps -> candidate list of launch k; others stay pending. One block.
-__global__ void k_seeds_to_active(DevParams P, int qz, int k) {
-    __shared__ int s_keep;
+// (device bodies: run by ONE workgroup; s_keep is a shared counter of the calling kernel)
+__device__ void seeds_to_active(const DevParams &P, int qz, int k, int &s_keep) {
     if (threadIdx.x == 0) s_keep = 0;
     __syncthreads();
     const int n = P.ctr->scount;
@@ -719,6 +841,11 @@ __global__ void k_seeds_to_active(DevParams P, int qz, int k) {
     __syncthreads();
     for (int i = threadIdx.x; i < s_keep; i += blockDim.x) P.slist[i] = P.slist2[i];
     if (threadIdx.x == 0) P.ctr->scount = s_keep;
+    __syncthreads();
+}
+__global__ void k_seeds_to_active(DevParams P, int qz, int k) {
+    __shared__ int s_keep;
+    seeds_to_active(P, qz, k, s_keep);
 }
 __global__ void k_touched_to_active(DevParams P, int qz, int k) {
     const int n = P.ctr->tcount;
@@ -729,8 +856,7 @@ __global__ void k_activate_list(DevParams P, int qz, int k, const int *tiles, in
 }
 // Phase start: parked tiles whose priority is now inside the bound go back to the candidate list
 // of launch k; the others stay parked.  One workgroup.
-__global__ void k_unpark(DevParams P, int qz, int k, float rbound) {
-    __shared__ int s_keep;
+__device__ void unpark(const DevParams &P, int qz, int k, float rbound, int &s_keep) {
     if (threadIdx.x == 0) s_keep = 0;
     __syncthreads();
     const int n = P.ctr->npark[qz];
@@ -754,6 +880,11 @@ __global__ void k_unpark(DevParams P, int qz, int k, float rbound) {
     __syncthreads();
     for (int i = threadIdx.x; i < s_keep; i += blockDim.x) list[i] = tmp[i];
     if (threadIdx.x == 0) P.ctr->npark[qz] = s_keep;
+    __syncthreads();
+}
+__global__ void k_unpark(DevParams P, int qz, int k, float rbound) {
+    __shared__ int s_keep;
+    unpark(P, qz, k, rbound, s_keep);
 }
 // smallest priority waiting in queue qz (list of launch k); one workgroup
 __global__ void k_queue_min(DevParams P, int qz, int k) {
@@ -775,7 +906,7 @@ __global__ void k_queue_min(DevParams P, int qz, int k) {
 // invalidation bound for this step: the current start key plus one ordering band
 // start of a step with a single map: counters, start elements and the consume flag in one launch
 struct StepBegin { int start[4]; int consume; int clear_lmax; float sx, sy; };
-__global__ void k_step_begin(DevParams P, StepBegin a) {
+__device__ __forceinline__ void step_begin(const DevParams &P, const StepBegin &a) {
     const int t = threadIdx.x;
     if (t == 0) {
         P.ctr->tcount = 0; P.ctr->expanded = 0; P.ctr->tile_visits = 0; P.ctr->tile_iters = 0; P.ctr->elem_evals = 0;
@@ -786,18 +917,22 @@ __global__ void k_step_begin(DevParams P, StepBegin a) {
     if (t == 0) { P.spos[0] = a.sx; P.spos[1] = a.sy; }
     if (a.clear_lmax) for (int i = t; i < LMAX; i += blockDim.x) P.lmax[i] = 0;
 }
-__global__ void k_prepare_bound(DevParams P, float margin) {
-    if (threadIdx.x || blockIdx.x) return;
+__global__ void k_step_begin(DevParams P, StepBegin a) { step_begin(P, a); }
+__device__ __forceinline__ void prepare_bound(const DevParams &P, float margin) {
     float b = 0.0f;
     for (int m = 0; m < P.nmaps; ++m) b = fmaxf(b, start_bound(P, m));
     P.ctr->rbound = P.focused ? b + margin : INFINITY;
     P.ctr->done = 0;
 }
+__global__ void k_prepare_bound(DevParams P, float margin) {
+    if (threadIdx.x || blockIdx.x) return;
+    prepare_bound(P, margin);
+}
 // After a blind batch of invalidation + lowering launches: are both queues drained below the
 // start's key, and did the invalidation bound reach the key the start ended up with?
 // kr / kl: index of the next launch of the raise / lower queue.  One workgroup.
-__global__ void k_check(DevParams P, int kr, int kl, float margin) {
-    __shared__ int s_m;
+// (s_m, s_done: shared words of the calling kernel; `record`: this workgroup writes the verdict)
+__device__ int replan_check(const DevParams &P, int kr, int kl, float margin, bool record, int &s_m, int &s_done) {
     if (threadIdx.x == 0) s_m = INFBITS;
     __syncthreads();
     const int n = P.ctr->cnt[Q_RAISE][kr % 3];
@@ -810,18 +945,29 @@ __global__ void k_check(DevParams P, int kr, int kl, float margin) {
     }
     if (lmin != INFBITS) atomicMin(&s_m, lmin);
     __syncthreads();
-    if (threadIdx.x) return;
-    float bnew = 0.0f;
-    for (int m = 0; m < P.nmaps; ++m) bnew = fmaxf(bnew, start_bound(P, m));
-    const bool raise_done = P.ctr->cnt[Q_RAISE][kr % 3] == 0 || P.ctr->rel[Q_RAISE][(kr + 2) % 3] == 0;
-    const bool lower_done = P.ctr->cnt[Q_LOWER][kl % 3] == 0 || P.ctr->rel[Q_LOWER][(kl + 2) % 3] == 0;
-    const bool again = P.focused && (__int_as_float(s_m) < bnew);
-    if (again) P.ctr->rbound = fmaxf(bnew, P.ctr->rbound) + margin;
-    P.ctr->qmin[Q_RAISE] = s_m;
-    P.ctr->done = (raise_done && lower_done && !again) ? 1 : 0;
-    unsigned int upd = 0;
-    for (int m = 0; m < P.nmaps; ++m) if (P.consume[m]) { upd += P.num_updated[m]; P.num_updated[m] = 0; }
-    P.ctr->updated = upd;
+    if (threadIdx.x == 0) {
+        float bnew = 0.0f;
+        for (int m = 0; m < P.nmaps; ++m) bnew = fmaxf(bnew, start_bound(P, m));
+        const bool raise_done = P.ctr->cnt[Q_RAISE][kr % 3] == 0 || P.ctr->rel[Q_RAISE][(kr + 2) % 3] == 0;
+        const bool lower_done = P.ctr->cnt[Q_LOWER][kl % 3] == 0 || P.ctr->rel[Q_LOWER][(kl + 2) % 3] == 0;
+        const bool again = P.focused && (__int_as_float(s_m) < bnew);
+        const int done = (raise_done && lower_done && !again) ? 1 : 0;
+        s_done = done;
+        if (record) {
+            if (again) P.ctr->rbound = fmaxf(bnew, P.ctr->rbound) + margin;
+            P.ctr->qmin[Q_RAISE] = s_m;
+            P.ctr->done = done;
+            unsigned int upd = 0;
+            for (int m = 0; m < P.nmaps; ++m) if (P.consume[m]) { upd += P.num_updated[m]; P.num_updated[m] = 0; }
+            P.ctr->updated = upd;
+        }
+    }
+    __syncthreads();
+    return s_done;
+}
+__global__ void k_check(DevParams P, int kr, int kl, float margin) {
+    __shared__ int s_m, s_done;
+    replan_check(P, kr, kl, margin, true, s_m, s_done);
 }
 __global__ void k_start_bound(DevParams P) {
     const int m = blockIdx.x * blockDim.x + threadIdx.x;
@@ -838,8 +984,7 @@ __global__ void k_cost_stats(const uint8_t *cm, size_t n, int thr, unsigned long
     if ((threadIdx.x & 63) == 0) { atomicAdd(&out[0], s); atomicAdd(&out[1], c); }
 }
 // count elements whose G differs from the snapshot taken at first touch; release the tiles
-__global__ __launch_bounds__(T * T) void k_finalize(DevParams P, int only_if_done) {
-    if (only_if_done && !P.ctr->done) return;
+__device__ __forceinline__ void finalize_tiles(const DevParams &P) {
     const int n = P.ctr->tcount;
     const int io_r = threadIdx.x / T, io_c = threadIdx.x % T;
     for (int i = blockIdx.x; i < n; i += gridDim.x) {
@@ -854,6 +999,79 @@ __global__ __launch_bounds__(T * T) void k_finalize(DevParams P, int only_if_don
             P.touched[gt] = 0;
         }
     }
+}
+__global__ __launch_bounds__(T * T) void k_finalize(DevParams P, int only_if_done) {
+    if (only_if_done && !P.ctr->done) return;
+    finalize_tiles(P);
+}
+// Replan, end of the submission in one launch instead of three: every workgroup evaluates the
+// device-side end condition (the queues are short; workgroup 0 records the verdict), finalises its
+// share of the touched tiles if the replan is complete, and the last workgroup to finish writes the
+// counters into host-coherent memory and bumps the sequence number the host spins on.
+__global__ __launch_bounds__(T * T) void k_replan_end(DevParams P, int kr, int kl, float margin,
+                                                      DevCounters *host, unsigned int *flag, unsigned int seq) {
+    __shared__ int s_m, s_done, s_last;
+    kr = launch_index(P, Q_RAISE, kr);
+    kl = launch_index(P, Q_LOWER, kl);
+    if (seq == 0) seq = P.ctr->pubseq;
+    const int done = replan_check(P, kr, kl, margin, blockIdx.x == 0, s_m, s_done);
+    if (done) finalize_tiles(P);
+    __threadfence();
+    __syncthreads();
+    if (threadIdx.x == 0) s_last = (atomicAdd(&P.ctr->fin_blocks, 1) == (int)gridDim.x - 1);
+    __syncthreads();
+    if (!s_last) return;
+    __threadfence();
+    if (threadIdx.x == 0) P.ctr->fin_blocks = 0;
+    const int *src = reinterpret_cast<const int *>(P.ctr);
+    int *dst = reinterpret_cast<int *>(host);
+    for (int i = threadIdx.x; i < (int)(sizeof(DevCounters) / sizeof(int)); i += blockDim.x)
+        dst[i] = __hip_atomic_load(&src[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_store(flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+// Replan, single map: everything between "the patches are in" and the first invalidation launch
+// in one workgroup -- step bookkeeping, mark reset of the consumed patch rectangles, seeds into the
+// invalidation queue, the invalidation bound, parked invalidations below it.  (Each separate
+// launch costs ~5 us of dispatch latency; a replan used to begin with five of them.)
+struct ReplanBegin { StepBegin sb; int nrect; int rect[4][5]; int k_raise; float band; };
+__device__ void replan_begin(const DevParams &P, const ReplanBegin &a, int &s_keep) {
+    step_begin(P, a.sb);
+    for (int r = 0; r < a.nrect; ++r) {
+        const int *q = a.rect[r];
+        for (int e = threadIdx.x; e < (q[3] + 1) * (q[4] + 1); e += blockDim.x) clear_mark(P, q[0], q[1], q[2], q[3], q[4], e);
+    }
+    __syncthreads();
+    seeds_to_active(P, Q_RAISE, a.k_raise, s_keep);
+    if (threadIdx.x == 0) prepare_bound(P, a.band);
+    __syncthreads();
+    unpark(P, Q_RAISE, a.k_raise, -1.0f, s_keep);
+}
+__global__ __launch_bounds__(1024) void k_replan_begin(DevParams P, ReplanBegin a) {
+    __shared__ int s_keep;
+    replan_begin(P, a, s_keep);
+}
+// first node of the replan graph: the per-replan inputs come from host-coherent memory
+struct ReplanJob { ReplanBegin rb; int k_lower; unsigned int seq; };
+__global__ __launch_bounds__(1024) void k_replan_begin_job(DevParams P, const ReplanJob *job) {
+    __shared__ int s_keep;
+    __shared__ ReplanJob s_job;
+    for (int i = threadIdx.x; i < (int)(sizeof(ReplanJob) / sizeof(int)); i += blockDim.x)
+        reinterpret_cast<int *>(&s_job)[i] = __hip_atomic_load(reinterpret_cast<const int *>(job) + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        P.ctr->kbase[Q_RAISE] = s_job.rb.k_raise; P.ctr->kbase[Q_LOWER] = s_job.k_lower; P.ctr->pubseq = s_job.seq;
+    }
+    replan_begin(P, s_job.rb, s_keep);
+}
+// ... and between the invalidation and the lowering launches
+__global__ __launch_bounds__(1024) void k_raise_to_lower(DevParams P, int k_lower) {
+    __shared__ int s_keep;
+    k_lower = launch_index(P, Q_LOWER, k_lower);
+    const int n = P.ctr->tcount;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) activate(P, Q_LOWER, k_lower % 3, k_lower & 1, P.tlist[i], 0);
+    unpark(P, Q_LOWER, k_lower, INFINITY, s_keep);
 }
 
 // ---- host side -------------------------------------------------------------------
@@ -887,7 +1105,20 @@ struct Engine {
     DevParams P{};
     bool allocated = false;
     hipStream_t stream = nullptr;
-    DevCounters *h_ctr = nullptr;    // pinned
+    DevCounters *h_ctr = nullptr;    // pinned, host-coherent: k_publish writes it, the host spins on h_flag
+    unsigned int *h_flag = nullptr;  // sequence number of the last published copy (same allocation)
+    unsigned int pub_seq = 0;
+    bool spin_wait = true;           // false: hipMemcpyAsync + hipStreamSynchronize instead
+    bool fuse_control = true;        // replans: fused control kernels (k_replan_begin / _raise_to_lower / _end)
+    bool use_graph = true;           // replans: the whole submission replayed as one captured hipGraph
+    int batch_margin = 1;            // replans: launches per phase = most that the last 6 replans needed + this
+    ReplanJob *h_job = nullptr;      // host-coherent pinned: per-replan inputs of the graph's first node
+    struct GraphSig { DevParams P; float band, delta; int max_iters, grid; };
+    GraphSig graph_sig{};
+    std::vector<std::pair<int, hipGraphExec_t>> graphs;   // key nr * 256 + nl
+    int relax_kernel(int mode, int k_arg, float rbound);
+    int replan_graph(int nr, int nl, float band, hipGraphExec_t *out);
+    void drop_graphs() { for (auto &g : graphs) hipGraphExecDestroy(g.second); graphs.clear(); }
     int *h_scratch = nullptr;        // pinned, nmaps*4 ints
     int *d_scratch = nullptr;
     uint8_t *d_patch = nullptr;      // staging for host patches
@@ -904,9 +1135,9 @@ struct Engine {
     bool focused = true;             // stop at the start's key like the reference (end_condition)
     bool dynamic_mode = true;        // long queues: k_triage + cursor hand-out
     float *h_bnd = nullptr;          // pinned [nmaps]
-    int hist_raise = 3, hist_lower = 4;   // blind batch sizes of the replan fast path
     int last_active = 1;             // queue length at the last host check: long queues go through k_triage
     int grid_relax = 512;
+    int small_grid = 1 << 30;        // workgroups of a relax launch over a short queue (measured: no gain, off)
     int max_iters = 32;              // sweep cap per tile visit (x4 patch sweeps per wave): a tile that needs more is
                                      // re-queued instead of holding the whole launch (measured optimum on 4096^2)
     float delta_abs = -1.0f;         // ordering band; < 0: delta_scale * T * mean traversable cost
@@ -920,6 +1151,9 @@ struct Engine {
     int alloc(int width, int length);
     void release();
     int launch_relax(int mode, float rbound, hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr);
+    int fetch_counters();
+    int wait_published();
+    int win_raise[6] = {3, 3, 3, 3, 3, 3}, win_lower[6] = {4, 4, 4, 4, 4, 4}, win_pos = 0;   // launches recent replans needed
     int run_phase(int mode, float rbound, uint32_t *launches, float *kernel_ms);
     int reset_queues();
     int read_bounds(float *bmax);
@@ -929,7 +1163,7 @@ struct Engine {
 
 void Engine::release() {
     if (!allocated) return;
-    hipFree(P.G); hipFree(P.Gprev); hipFree(P.cost); hipFree(P.goal); hipFree(P.cand); hipFree(P.ready); hipFree(P.park); hipFree(P.pflag); hipFree(P.pprio); hipFree(P.queued); hipFree(P.prio); hipFree(P.start); hipFree(P.bnd); hipFree(P.spos);
+    hipFree(P.G); hipFree(P.Gprev); hipFree(P.cost); hipFree(P.goal); hipFree(P.cand); hipFree(P.ready); hipFree(P.hint); hipFree(P.park); hipFree(P.pflag); hipFree(P.pprio); hipFree(P.queued); hipFree(P.prio); hipFree(P.start); hipFree(P.bnd); hipFree(P.spos);
     hipFree(P.touched); hipFree(P.tlist); hipFree(P.sflag); hipFree(P.slist); hipFree(P.slist2);
     hipFree(P.mark); hipFree(P.num_updated); hipFree(P.consume); hipFree(P.lmax); hipFree(P.ctr);
     hipFree(d_scratch);
@@ -960,6 +1194,9 @@ int Engine::alloc(int width, int length) {
     HIPCHK(hipMalloc(&P.goal, sizeof(int) * 2 * nmaps));
     HIPCHK(hipMalloc(&P.cand, sizeof(int) * 6 * P.NT));
     HIPCHK(hipMalloc(&P.ready, sizeof(int) * P.NT));
+    HIPCHK(hipMalloc(&P.hint, sizeof(int) * P.NT));
+
+    HIPCHK(hipMemsetAsync(P.hint, 0, sizeof(int) * P.NT, stream));
     HIPCHK(hipMalloc(&P.park, sizeof(int) * 4 * P.NT));
     HIPCHK(hipMalloc(&P.pflag, sizeof(int) * 2 * P.NT));
     HIPCHK(hipMalloc(&P.pprio, sizeof(int) * 2 * P.NT));
@@ -1003,7 +1240,7 @@ int Engine::reset_queues() {
     k_fill<<<64, 256, 0, stream>>>(reinterpret_cast<float *>(P.prio), (size_t)4 * P.NT, INFINITY);
     HIPCHK(hipMemsetAsync(P.pflag, 0, sizeof(int) * 2 * P.NT, stream));
     k_fill<<<64, 256, 0, stream>>>(reinterpret_cast<float *>(P.pprio), (size_t)2 * P.NT, INFINITY);
-    HIPCHK(hipMemsetAsync(P.ctr->cnt, 0, sizeof(int) * 24, stream));   // cnt, rel, lmin, npark, nready, rcursor
+    HIPCHK(hipMemsetAsync(P.ctr->cnt, 0, sizeof(int) * 29, stream));   // cnt, rel, lmin, npark, nready, rcursor, nshort, last_work, fin_blocks
     k_fill<<<1, 64, 0, stream>>>(reinterpret_cast<float *>(&P.ctr->lmin[0][0]), (size_t)6, INFINITY);
     last_active = 1;
     iter[0] = iter[1] = 0;
@@ -1020,14 +1257,101 @@ int Engine::read_bounds(float *bmax) {
     return UFM_OK;
 }
 
+// Counters to the host.  A D2H copy + hipStreamSynchronize costs ~40 us of wake-up latency per
+// host round trip (measured: copy done at 289 us, host running again at 327 us); a replan has one
+// round trip, a plan one per batch of launches.  Instead the last kernel of a submission writes
+// the counters into host-coherent pinned memory, fences, and bumps a sequence number the host
+// spins on (the reference's driver owns its core anyway, main.cpp:36-47).
+__global__ void k_publish(const DevCounters *src, DevCounters *dst, unsigned int *flag, unsigned int seq) {
+    const int *s = reinterpret_cast<const int *>(src);
+    int *d = reinterpret_cast<int *>(dst);
+    for (int i = threadIdx.x; i < (int)(sizeof(DevCounters) / sizeof(int)); i += blockDim.x) d[i] = s[i];
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_store(flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+int Engine::fetch_counters() {
+    if (!spin_wait) {
+        HIPCHK(hipMemcpyAsync(h_ctr, P.ctr, sizeof(DevCounters), hipMemcpyDeviceToHost, stream));
+        HIPCHK(hipStreamSynchronize(stream));
+        return UFM_OK;
+    }
+    ++pub_seq;
+    k_publish<<<1, 64, 0, stream>>>(P.ctr, h_ctr, h_flag, pub_seq);
+    HIPCHK(hipGetLastError());
+    return wait_published();
+}
+// spin until the device has published copy number pub_seq
+int Engine::wait_published() {
+    const auto t0 = std::chrono::steady_clock::now();
+    for (unsigned int spins = 1;; ++spins) {
+        if (__atomic_load_n(h_flag, __ATOMIC_ACQUIRE) == pub_seq) return UFM_OK;
+        __builtin_ia32_pause();
+        // a faulted kernel never publishes: after 20 s ask the runtime what happened
+        if ((spins & 0xFFFF) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(20)) break;
+    }
+    HIPCHK(hipStreamSynchronize(stream));
+    return __atomic_load_n(h_flag, __ATOMIC_ACQUIRE) == pub_seq ? UFM_OK : UFM_ERR_HIP_BASE;
+}
+
+// one relax launch over a short queue (fused triage) with an explicit launch-index argument
+int Engine::relax_kernel(int mode, int k_arg, float rbound) {
+    const dim3 g(grid_relax), b(NTHR);
+    const float delta = (mode == MODE_RAISE) ? INFINITY : (delta_abs >= 0.0f ? delta_abs : delta_scale * T * mean_cost);
+#define UFM_LAUNCH(A, M) k_relax<A, M, false><<<g, b, 0, stream>>>(P, k_arg, delta, rbound, max_iters)
+    if (mode == MODE_LOWER) {
+        if (algo == UFM_ALGO_FD) UFM_LAUNCH(UFM_ALGO_FD, MODE_LOWER);
+        else if (algo == UFM_ALGO_SG) UFM_LAUNCH(UFM_ALGO_SG, MODE_LOWER);
+        else UFM_LAUNCH(UFM_ALGO_DFM, MODE_LOWER);
+    } else {
+        if (algo == UFM_ALGO_FD) UFM_LAUNCH(UFM_ALGO_FD, MODE_RAISE);
+        else if (algo == UFM_ALGO_SG) UFM_LAUNCH(UFM_ALGO_SG, MODE_RAISE);
+        else UFM_LAUNCH(UFM_ALGO_DFM, MODE_RAISE);
+    }
+#undef UFM_LAUNCH
+    return UFM_OK;
+}
+// The whole replan submission -- begin, nr invalidation launches, transition, nl lowering
+// launches, end -- captured once per (nr, nl) and replayed: the host enqueues one graph instead of
+// ~20 kernels (2.9 us of host time each, measured; the kernels of a replan are that short).  The
+// graph is static: launch indices are offsets to a base the first node takes, with the rest of
+// the per-replan inputs, from host-coherent memory (h_job).
+int Engine::replan_graph(int nr, int nl, float band, hipGraphExec_t *out) {
+    GraphSig sig{};
+    sig.P = P; sig.band = band; sig.delta = delta_abs >= 0.0f ? delta_abs : delta_scale * T * mean_cost;
+    sig.max_iters = max_iters; sig.grid = grid_relax;
+    if (std::memcmp(&sig, &graph_sig, sizeof(GraphSig)) != 0) { drop_graphs(); std::memcpy(&graph_sig, &sig, sizeof(GraphSig)); }
+    const int key = nr * 256 + nl;
+    for (auto &g : graphs) if (g.first == key) { *out = g.second; return UFM_OK; }
+    if (graphs.size() >= 64) drop_graphs();
+    HIPCHK(hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal));
+    k_replan_begin_job<<<1, 1024, 0, stream>>>(P, h_job);
+    for (int i = 0; i < nr; ++i) relax_kernel(MODE_RAISE, -1 - i, -1.0f);
+    k_raise_to_lower<<<1, 1024, 0, stream>>>(P, -1);
+    for (int i = 0; i < nl; ++i) relax_kernel(MODE_LOWER, -1 - i, INFINITY);
+    k_replan_end<<<64, T * T, 0, stream>>>(P, -1 - nr, -1 - nl, band, h_ctr, h_flag, 0u);
+    hipGraph_t g = nullptr;
+    HIPCHK(hipStreamEndCapture(stream, &g));
+    hipGraphExec_t ge = nullptr;
+    const hipError_t err = hipGraphInstantiate(&ge, g, nullptr, nullptr, 0);
+    hipGraphDestroy(g);
+    HIPCHK(err);
+    graphs.emplace_back(key, ge);
+    *out = ge;
+    return UFM_OK;
+}
+
 // e0 / e1 (profiling): HIP events recorded on the engine's stream right around the relax kernel
 int Engine::launch_relax(int mode, float rbound, hipEvent_t e0, hipEvent_t e1) {
-    const dim3 g(grid_relax), b(NTHR);
+    dim3 g(grid_relax), b(NTHR);
     // invalidation is order-free; lowering releases tiles in bands of `delta`
     const float delta = (mode == MODE_RAISE) ? INFINITY : (delta_abs >= 0.0f ? delta_abs : delta_scale * T * mean_cost);
     const int q = (mode == MODE_LOWER) ? Q_LOWER : Q_RAISE;
     // long queue: vectorised triage + balanced hand-out of the released tiles; short queue: fused
     const bool dyn = dynamic_mode && last_active > grid_relax / 4;
+    // a short queue (replans: a handful of tiles per launch) does not need the whole chip: a small
+    // grid starts, and when there is nothing left to do ends, sooner
+    if (!dyn && last_active <= small_grid / 2 && small_grid < grid_relax) g = dim3(small_grid);
     if (dyn) {
         if (mode == MODE_LOWER) k_triage<MODE_LOWER><<<64, 256, 0, stream>>>(P, iter[q], delta, rbound);
         else k_triage<MODE_RAISE><<<64, 256, 0, stream>>>(P, iter[q], delta, rbound);
@@ -1074,8 +1398,7 @@ int Engine::run_phase(int mode, float rbound, uint32_t *launches, float *kernel_
         HIPCHK(hipGetLastError());
         *launches += (uint32_t)batch;
         total += batch;
-        HIPCHK(hipMemcpyAsync(h_ctr, P.ctr, sizeof(DevCounters), hipMemcpyDeviceToHost, stream));
-        HIPCHK(hipStreamSynchronize(stream));
+        { int rc = fetch_counters(); if (rc != UFM_OK) return rc; }
         if (profiling)
             for (int k = 0; k < batch; ++k) {
                 float ms = 0;
@@ -1100,10 +1423,15 @@ int Engine::patch(int m, const uint8_t *dev_patch, int x, int y, int w, int h) {
         d_pmask_cap = n < 4096 ? 4096 : (size_t)n;
         HIPCHK(hipMalloc(&d_pmask, d_pmask_cap));
     }
-    k_patch_apply<<<(n + 255) / 256, 256, 0, stream>>>(P, m, dev_patch, d_pmask, x, y, w, h);
-    const int ne = (w + 1) * (h + 1);
-    if (algo == UFM_ALGO_DFM) k_patch_seed<false><<<(ne + 255) / 256, 256, 0, stream>>>(P, m, d_pmask, x, y, w, h);
-    else k_patch_seed<true><<<(ne + 255) / 256, 256, 0, stream>>>(P, m, d_pmask, x, y, w, h);
+    if (n <= 4096) {
+        if (algo == UFM_ALGO_DFM) k_patch_small<false><<<1, 1024, 0, stream>>>(P, m, dev_patch, d_pmask, x, y, w, h);
+        else k_patch_small<true><<<1, 1024, 0, stream>>>(P, m, dev_patch, d_pmask, x, y, w, h);
+    } else {
+        k_patch_apply<<<(n + 255) / 256, 256, 0, stream>>>(P, m, dev_patch, d_pmask, x, y, w, h);
+        const int ne = (w + 1) * (h + 1);
+        if (algo == UFM_ALGO_DFM) k_patch_seed<false><<<(ne + 255) / 256, 256, 0, stream>>>(P, m, d_pmask, x, y, w, h);
+        else k_patch_seed<true><<<(ne + 255) / 256, 256, 0, stream>>>(P, m, d_pmask, x, y, w, h);
+    }
     HIPCHK(hipGetLastError());
     pending.push_back({m, x, y, w, h});
     return UFM_OK;
@@ -1156,6 +1484,12 @@ int Engine::step(ufm_stats *out) {
         if (ms.initialize_search || ms.new_goal)
             HIPCHK(hipMemcpyAsync(P.goal + 2 * m, goals + 2 * m, 2 * sizeof(int), hipMemcpyHostToDevice, stream));
     }
+    // replan of a single map with a few small pending patches: the control steps run fused
+    // (k_replan_begin / k_raise_to_lower / k_replan_end) instead of as ten separate launches
+    ReplanBegin rb{};
+    bool fused = single && fuse_control && spin_wait && n_init == 0 && n_upd > 0 && !pending.empty() && pending.size() <= 4;
+    if (fused)
+        for (const PatchRect &r : pending) fused = fused && consume[r.m] && (r.w + 1) * (r.h + 1) <= 65 * 65;
     {   // start elements: the 4 corners of the start cell (FD impl:9-13, Cell.cpp:48-60) / the start cell (DFM)
         int *st_el = h_scratch + 5 * nmaps + 4;
         float *sp = reinterpret_cast<float *>(h_scratch + 9 * nmaps + 8);
@@ -1175,12 +1509,11 @@ int Engine::step(ufm_stats *out) {
             }
         }
         if (single) {
-            StepBegin sb;
-            for (int i = 0; i < 4; ++i) sb.start[i] = st_el[i];
-            sb.consume = consume[0];
-            sb.clear_lmax = profiling ? 1 : 0;
-            sb.sx = sp[0]; sb.sy = sp[1];
-            k_step_begin<<<1, 256, 0, stream>>>(P, sb);
+            for (int i = 0; i < 4; ++i) rb.sb.start[i] = st_el[i];
+            rb.sb.consume = consume[0];
+            rb.sb.clear_lmax = profiling ? 1 : 0;
+            rb.sb.sx = sp[0]; rb.sb.sy = sp[1];
+            if (!fused) k_step_begin<<<1, 256, 0, stream>>>(P, rb.sb);
         } else {
             HIPCHK(hipMemcpyAsync(P.start, st_el, sizeof(int) * 4 * nmaps, hipMemcpyHostToDevice, stream));
             HIPCHK(hipMemcpyAsync(P.spos, sp, sizeof(float) * 2 * nmaps, hipMemcpyHostToDevice, stream));
@@ -1198,7 +1531,8 @@ int Engine::step(ufm_stats *out) {
             if (!consume[r.m]) { keep.push_back(r); continue; }
             have_seeds = true;
             const int cnt = (r.h + 1) * (r.w + 1);
-            k_clear_marks<<<(cnt + 255) / 256, 256, 0, stream>>>(P, r.m, r.x, r.y, r.w, r.h);
+            if (fused) { int *q = rb.rect[rb.nrect++]; q[0] = r.m; q[1] = r.x; q[2] = r.y; q[3] = r.w; q[4] = r.h; }
+            else k_clear_marks<<<(cnt + 255) / 256, 256, 0, stream>>>(P, r.m, r.x, r.y, r.w, r.h);
         }
         pending.swap(keep);
     }
@@ -1209,10 +1543,32 @@ int Engine::step(ufm_stats *out) {
         // lowering launches -> device-side check -> finalise if the check says "done".  (An empty
         // launch costs a few microseconds; a host round trip costs more.)  If the batches were too
         // short the general adaptive loop below takes over.
-        k_seeds_to_active<<<1, 1024, 0, stream>>>(P, Q_RAISE, iter[Q_RAISE]);
-        k_prepare_bound<<<1, 64, 0, stream>>>(P, band);
-        k_unpark<<<1, 1024, 0, stream>>>(P, Q_RAISE, iter[Q_RAISE], -1.0f);
-        const int nr = hist_raise + 2, nl = hist_lower + 2;
+        // blind batch sizes: what the recent replans needed, plus one
+        int nr = 1, nl = 1;
+        for (int i = 0; i < 6; ++i) { nr = std::max(nr, win_raise[i] + batch_margin); nl = std::max(nl, win_lower[i] + batch_margin); }
+        const int k0_raise = iter[Q_RAISE], k0_lower = iter[Q_LOWER];
+        const bool graphed = fused && use_graph && !profiling && nr < 250 && nl < 250;
+        if (graphed) {
+            rb.k_raise = iter[Q_RAISE]; rb.band = band;
+            hipGraphExec_t ge = nullptr;
+            int rc = replan_graph(nr, nl, band, &ge);
+            if (rc != UFM_OK) return rc;
+            h_job->rb = rb; h_job->k_lower = iter[Q_LOWER]; h_job->seq = ++pub_seq;
+            __atomic_thread_fence(__ATOMIC_RELEASE);
+            HIPCHK(hipGraphLaunch(ge, stream));
+            iter[Q_RAISE] += nr; iter[Q_LOWER] += nl;
+            last_active = 1;
+            rc = wait_published();
+            if (rc != UFM_OK) return rc;
+        } else {
+        if (fused) {
+            rb.k_raise = iter[Q_RAISE]; rb.band = band;
+            k_replan_begin<<<1, 1024, 0, stream>>>(P, rb);
+        } else {
+            k_seeds_to_active<<<1, 1024, 0, stream>>>(P, Q_RAISE, iter[Q_RAISE]);
+            k_prepare_bound<<<1, 64, 0, stream>>>(P, band);
+            k_unpark<<<1, 1024, 0, stream>>>(P, Q_RAISE, iter[Q_RAISE], -1.0f);
+        }
         hipEvent_t e0 = nullptr, e1 = nullptr, e2 = nullptr, e3 = nullptr;
         if (profiling) {
             while (ev.size() < 4) { hipEvent_t a; HIPCHK(hipEventCreate(&a)); ev.push_back(a); }
@@ -1222,29 +1578,47 @@ int Engine::step(ufm_stats *out) {
         last_active = 1;             // replans touch a handful of tiles: fused triage
         for (int i = 0; i < nr; ++i) launch_relax(MODE_RAISE, -1.0f);
         if (profiling) HIPCHK(hipEventRecord(e1, stream));
-        k_touched_to_active<<<64, 256, 0, stream>>>(P, Q_LOWER, iter[Q_LOWER]);
-        k_unpark<<<1, 1024, 0, stream>>>(P, Q_LOWER, iter[Q_LOWER], INFINITY);
+        if (fused) {
+            k_raise_to_lower<<<1, 1024, 0, stream>>>(P, iter[Q_LOWER]);
+        } else {
+            k_touched_to_active<<<64, 256, 0, stream>>>(P, Q_LOWER, iter[Q_LOWER]);
+            k_unpark<<<1, 1024, 0, stream>>>(P, Q_LOWER, iter[Q_LOWER], INFINITY);
+        }
         if (profiling) HIPCHK(hipEventRecord(e2, stream));
         for (int i = 0; i < nl; ++i) launch_relax(MODE_LOWER, INFINITY);
         if (profiling) HIPCHK(hipEventRecord(e3, stream));
-        k_check<<<1, 1024, 0, stream>>>(P, iter[Q_RAISE], iter[Q_LOWER], band);
-        k_finalize<<<grid_relax, T * T, 0, stream>>>(P, 1);
-        HIPCHK(hipMemcpyAsync(h_ctr, P.ctr, sizeof(DevCounters), hipMemcpyDeviceToHost, stream));
-        HIPCHK(hipGetLastError());
-        HIPCHK(hipStreamSynchronize(stream));
+        if (fused) {
+            ++pub_seq;
+            k_replan_end<<<64, T * T, 0, stream>>>(P, iter[Q_RAISE], iter[Q_LOWER], band, h_ctr, h_flag, pub_seq);
+            HIPCHK(hipGetLastError());
+            int rc = wait_published();
+            if (rc != UFM_OK) return rc;
+        } else {
+            k_check<<<1, 1024, 0, stream>>>(P, iter[Q_RAISE], iter[Q_LOWER], band);
+            k_finalize<<<grid_relax, T * T, 0, stream>>>(P, 1);
+            HIPCHK(hipGetLastError());
+            int rc = fetch_counters();
+            if (rc != UFM_OK) return rc;
+        }
         if (profiling) {
             float ms = 0;
             HIPCHK(hipEventElapsedTime(&ms, e0, e1)); st.kernel_ms += ms; st.raise_kernel_ms += ms;
             HIPCHK(hipEventElapsedTime(&ms, e2, e3)); st.kernel_ms += ms;
         }
+        }   // !graphed
         updated += h_ctr->updated;
         st.raise_launches += (uint32_t)nr;
         st.launches += (uint32_t)(nr + nl);
         fast_done = h_ctr->done != 0;
-        // launches the batches actually needed (for the next step's batch sizes)
-        hist_raise = hist_raise > 1 ? hist_raise - 1 : 1;
-        hist_lower = hist_lower > 1 ? hist_lower - 1 : 1;
-        if (!fast_done) { hist_raise += 3; hist_lower += 3; }
+        // launches the batches actually needed (for the next steps' batch sizes); a batch that was
+        // too short costs a host round trip and the adaptive loop, so err on the long side after one
+        {
+            const int need_r = std::max(0, h_ctr->last_work[Q_RAISE] - k0_raise + 1);
+            const int need_l = std::max(0, h_ctr->last_work[Q_LOWER] - k0_lower + 1);
+            win_raise[win_pos] = fast_done ? need_r : nr + 2;
+            win_lower[win_pos] = fast_done ? need_l : nl + 2;
+            win_pos = (win_pos + 1) % 6;
+        }
     } else if (have_seeds) {
         // num_nodes_updated (FD impl:138, DFM impl:109) of the participating maps
         HIPCHK(hipMemcpyAsync(h_scratch + 2 * nmaps + 2 * nmaps, P.num_updated, sizeof(unsigned int) * nmaps, hipMemcpyDeviceToHost, stream));
@@ -1318,8 +1692,8 @@ int Engine::step(ufm_stats *out) {
                 rc = read_bounds(&bnew);
                 if (rc != UFM_OK) return rc;
                 k_queue_min<<<1, 1024, 0, stream>>>(P, Q_RAISE, iter[Q_RAISE]);
-                HIPCHK(hipMemcpyAsync(h_ctr, P.ctr, sizeof(DevCounters), hipMemcpyDeviceToHost, stream));
-                HIPCHK(hipStreamSynchronize(stream));
+                rc = fetch_counters();
+                if (rc != UFM_OK) return rc;
                 float qm;
                 std::memcpy(&qm, &h_ctr->qmin[Q_RAISE], sizeof(float));
                 if (qm < bnew) { again = true; rbound = std::fmax(bnew, rbound) + band; }
@@ -1331,8 +1705,7 @@ int Engine::step(ufm_stats *out) {
         }
         const auto td = std::chrono::steady_clock::now();
         k_finalize<<<grid_relax, T * T, 0, stream>>>(P, 0);
-        HIPCHK(hipMemcpyAsync(h_ctr, P.ctr, sizeof(DevCounters), hipMemcpyDeviceToHost, stream));
-        HIPCHK(hipStreamSynchronize(stream));
+        { int rc = fetch_counters(); if (rc != UFM_OK) return rc; }
         st.expanded = h_ctr->expanded;
         st.tile_visits = h_ctr->tile_visits;
         st.tile_iters = h_ctr->tile_iters;
@@ -1382,7 +1755,18 @@ int engine_create(Engine **out, int n_maps, int algo, int opt_lvl, int use_heuri
     HIPCHK(hipGetDeviceProperties(&prop, device_id));
     e->grid_relax = prop.multiProcessorCount * 2;
     HIPCHK(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
-    HIPCHK(hipHostMalloc(&e->h_ctr, sizeof(DevCounters)));
+    {   // counters + sequence flag in one host-coherent, device-mapped allocation
+        const size_t flag_off = (sizeof(DevCounters) + 63) / 64 * 64;
+        void *pub = nullptr;
+        HIPCHK(hipHostMalloc(&pub, flag_off + 64, hipHostMallocMapped | hipHostMallocCoherent));
+        std::memset(pub, 0, flag_off + 64);
+        e->h_ctr = static_cast<DevCounters *>(pub);
+        e->h_flag = reinterpret_cast<unsigned int *>(static_cast<char *>(pub) + flag_off);
+        void *job = nullptr;
+        HIPCHK(hipHostMalloc(&job, sizeof(ReplanJob), hipHostMallocMapped | hipHostMallocCoherent));
+        std::memset(job, 0, sizeof(ReplanJob));
+        e->h_job = static_cast<ReplanJob *>(job);
+    }
     HIPCHK(hipHostMalloc(&e->h_scratch, sizeof(int) * (11 * n_maps + 16)));
     HIPCHK(hipHostMalloc(&e->h_bnd, sizeof(float) * n_maps));
     *out = e;
@@ -1402,7 +1786,9 @@ int engine_destroy(Engine *e) {
     if (e->d_path) hipFree(e->d_path);
     if (e->h_path) hipHostFree(e->h_path);
     if (e->h_patch) hipHostFree(e->h_patch);
+    e->drop_graphs();
     if (e->h_ctr) hipHostFree(e->h_ctr);
+    if (e->h_job) hipHostFree(e->h_job);
     if (e->h_scratch) hipHostFree(e->h_scratch);
     if (e->h_bnd) hipHostFree(e->h_bnd);
     if (e->stream) hipStreamDestroy(e->stream);
@@ -1546,6 +1932,23 @@ struct ufm_batch { Engine *e; };
 
 extern "C" {
 
+#ifdef UFM_TIMING
+int ufm_debug_trace(unsigned long long *out, int cap) {     // returns the number of records copied (4 words each)
+    unsigned int n = 0;
+    if (hipMemcpyFromSymbol(&n, HIP_SYMBOL(g_ntrace), sizeof(n)) != hipSuccess) return UFM_ERR_HIP_BASE;
+    if ((int)n > cap) n = cap;
+    if (n > 16384) n = 16384;
+    if (n && hipMemcpyFromSymbol(out, HIP_SYMBOL(g_trace), sizeof(unsigned long long) * 4 * n) != hipSuccess) return UFM_ERR_HIP_BASE;
+    const unsigned int z = 0;
+    hipMemcpyToSymbol(HIP_SYMBOL(g_ntrace), &z, sizeof(z));
+    return (int)n;
+}
+int ufm_debug_tdiag(unsigned long long *out, int reset) {
+    if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(g_tdiag), sizeof(unsigned long long) * 64) != hipSuccess) return UFM_ERR_HIP_BASE;
+    if (reset) { unsigned long long z[64] = {}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_tdiag), z, sizeof(z)) != hipSuccess) return UFM_ERR_HIP_BASE; }
+    return UFM_OK;
+}
+#endif
 int ufm_tile_edge(void) { return T; }
 const char *ufm_version(void) { return T == 32 ? "ufm-gfx950 0.1 (block-FIM, tile 32)" : "ufm-gfx950 0.1 (block-FIM, tile 16)"; }
 
@@ -1609,6 +2012,11 @@ int ufm_set_param(ufm_t *p, const char *name, double value) {
     else if (!std::strcmp(name, "max_iters")) e->max_iters = value < 1 ? 1 : (int)value;
     else if (!std::strcmp(name, "batch")) e->batch_fixed = (int)value;
     else if (!std::strcmp(name, "grid")) e->grid_relax = value < 1 ? 1 : (int)value;
+    else if (!std::strcmp(name, "small_grid")) e->small_grid = value < 1 ? 1 : (int)value;
+    else if (!std::strcmp(name, "spin_wait")) e->spin_wait = value != 0;
+    else if (!std::strcmp(name, "fuse_control")) e->fuse_control = value != 0;
+    else if (!std::strcmp(name, "graph")) e->use_graph = value != 0;
+    else if (!std::strcmp(name, "batch_margin")) e->batch_margin = (int)value;
     else if (!std::strcmp(name, "focused")) e->focused = value != 0.0;
     else if (!std::strcmp(name, "dynamic")) e->dynamic_mode = value != 0.0;
     else return UFM_ERR_INVALID;
