@@ -1116,7 +1116,8 @@ struct Engine {
     struct GraphSig { DevParams P; float band, delta; int max_iters, grid; };
     GraphSig graph_sig{};
     std::vector<std::pair<int, hipGraphExec_t>> graphs;   // key nr * 256 + nl
-    int relax_kernel(int mode, int k_arg, float rbound);
+    int relax_kernel(int mode, int k_arg, float rbound, int grid);
+    int tail_grid = 96;              // replan graph: workgroups of the later launches of a phase (few tiles left)
     int replan_graph(int nr, int nl, float band, hipGraphExec_t *out);
     void drop_graphs() { for (auto &g : graphs) hipGraphExecDestroy(g.second); graphs.clear(); }
     int *h_scratch = nullptr;        // pinned, nmaps*4 ints
@@ -1295,8 +1296,8 @@ int Engine::wait_published() {
 }
 
 // one relax launch over a short queue (fused triage) with an explicit launch-index argument
-int Engine::relax_kernel(int mode, int k_arg, float rbound) {
-    const dim3 g(grid_relax), b(NTHR);
+int Engine::relax_kernel(int mode, int k_arg, float rbound, int grid) {
+    const dim3 g(grid), b(NTHR);
     const float delta = (mode == MODE_RAISE) ? INFINITY : (delta_abs >= 0.0f ? delta_abs : delta_scale * T * mean_cost);
 #define UFM_LAUNCH(A, M) k_relax<A, M, false><<<g, b, 0, stream>>>(P, k_arg, delta, rbound, max_iters)
     if (mode == MODE_LOWER) {
@@ -1319,16 +1320,20 @@ int Engine::relax_kernel(int mode, int k_arg, float rbound) {
 int Engine::replan_graph(int nr, int nl, float band, hipGraphExec_t *out) {
     GraphSig sig{};
     sig.P = P; sig.band = band; sig.delta = delta_abs >= 0.0f ? delta_abs : delta_scale * T * mean_cost;
-    sig.max_iters = max_iters; sig.grid = grid_relax;
+    sig.max_iters = max_iters; sig.grid = grid_relax * 4096 + tail_grid;
     if (std::memcmp(&sig, &graph_sig, sizeof(GraphSig)) != 0) { drop_graphs(); std::memcpy(&graph_sig, &sig, sizeof(GraphSig)); }
     const int key = nr * 256 + nl;
     for (auto &g : graphs) if (g.first == key) { *out = g.second; return UFM_OK; }
     if (graphs.size() >= 64) drop_graphs();
     HIPCHK(hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal));
     k_replan_begin_job<<<1, 1024, 0, stream>>>(P, h_job);
-    for (int i = 0; i < nr; ++i) relax_kernel(MODE_RAISE, -1 - i, -1.0f);
+    // a phase starts with its largest launches; what is left after a few of them fits a small
+    // grid, which starts -- and, when the queue has run dry, ends -- sooner (an empty 512-workgroup
+    // launch lasts 4.6 us)
+    auto grid_of = [&](int i) { return i < 2 ? grid_relax : (i < 4 ? std::max(tail_grid, grid_relax / 2) : tail_grid); };
+    for (int i = 0; i < nr; ++i) relax_kernel(MODE_RAISE, -1 - i, -1.0f, std::min(grid_relax, grid_of(i)));
     k_raise_to_lower<<<1, 1024, 0, stream>>>(P, -1);
-    for (int i = 0; i < nl; ++i) relax_kernel(MODE_LOWER, -1 - i, INFINITY);
+    for (int i = 0; i < nl; ++i) relax_kernel(MODE_LOWER, -1 - i, INFINITY, std::min(grid_relax, grid_of(i)));
     k_replan_end<<<64, T * T, 0, stream>>>(P, -1 - nr, -1 - nl, band, h_ctr, h_flag, 0u);
     hipGraph_t g = nullptr;
     HIPCHK(hipStreamEndCapture(stream, &g));
@@ -2017,6 +2022,7 @@ int ufm_set_param(ufm_t *p, const char *name, double value) {
     else if (!std::strcmp(name, "fuse_control")) e->fuse_control = value != 0;
     else if (!std::strcmp(name, "graph")) e->use_graph = value != 0;
     else if (!std::strcmp(name, "batch_margin")) e->batch_margin = (int)value;
+    else if (!std::strcmp(name, "tail_grid")) e->tail_grid = value < 1 ? 1 : (int)value;
     else if (!std::strcmp(name, "focused")) e->focused = value != 0.0;
     else if (!std::strcmp(name, "dynamic")) e->dynamic_mode = value != 0.0;
     else return UFM_ERR_INVALID;
