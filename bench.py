@@ -112,17 +112,24 @@ def main():
                             sync=lambda: torch.cuda.current_stream().synchronize())
     meta = [(k, s, top, left) for (k, s, top, left, _) in script]
 
+    def step_stats(p):
+        st = p.stats
+        d = {"cells": st.expanded, "visits": st.tile_visits, "launches": st.launches, "kernel_ms": st.kernel_ms, "evals": st.elem_evals,
+             "lower_visits": 0, "lower_launches": 0, "lower_kernel_ms": 0.0, "lower_timed": 0}
+        timed = st.timed_launches - st.timed_raise_launches
+        if timed > 0:   # steps whose lowering launches carry HIP events: the plans (a sample of their launches);
+            #             the replans are replayed from a captured graph, whose nodes HIP events cannot time
+            d.update(lower_visits=st.tile_visits - st.raise_tile_visits, lower_launches=st.launches - st.raise_launches,
+                     lower_kernel_ms=st.kernel_ms - st.raise_kernel_ms, lower_timed=timed)
+        return d
+
     def run_one():
         return ep.run_episode(
             planner,
             set_map=lambda p: p.set_map_device(d_cost.data_ptr(), size, size),
             start=start, goal=goal, script=meta, stream=stream,
             apply_patch=lambda p, buf, top, left: p.patch_map_device(buf.data_ptr(), top, left, psz, psz),
-            read_stats=lambda p: {"cells": p.stats.expanded, "visits": p.stats.tile_visits, "launches": p.stats.launches,
-                                  "kernel_ms": p.stats.kernel_ms, "evals": p.stats.elem_evals,
-                                  "lower_visits": p.stats.tile_visits - p.stats.raise_tile_visits,
-                                  "lower_launches": p.stats.launches - p.stats.raise_launches,
-                                  "lower_kernel_ms": p.stats.kernel_ms - p.stats.raise_kernel_ms})
+            read_stats=step_stats)
 
     def barrier():
         torch.cuda.synchronize()
@@ -132,7 +139,7 @@ def main():
 
     dt, per_step = ep.timed_episodes(run_one, args.steps, args.warmup, barrier)
     tot = [sum(d[k] for d in per_step) for k in ("cells", "visits", "launches", "kernel_ms", "evals")]
-    low = [sum(d[k] for d in per_step) for k in ("lower_visits", "lower_launches", "lower_kernel_ms")]
+    low = [sum(d[k] for d in per_step) for k in ("lower_visits", "lower_launches", "lower_kernel_ms", "lower_timed")]
 
     cells, visits, launches, kms, evals = tot
     if dist is not None:
@@ -168,22 +175,25 @@ def main():
                 "elem_evals_per_step_rank0": evals / max(1, args.steps),
             },
         }
-        lvis, llaunch, lkms = low
-        if lkms > 0 and llaunch > 0:
+        lvis, llaunch, lkms, ltimed = low
+        if lkms > 0 and llaunch > 0 and ltimed > 0:
             # dominant kernel: k_relax<algo, LOWER>.  Algorithmic bytes = tile visits x (9 B per element
             # + halo) per SURVEY.md 8(d); duration = HIP events on the engine's stream around its launches.
-            achieved = lvis * BYTES_PER_TILE_VISIT / (lkms * 1e-3) / 1e9
+            # (the events bracket a sample of the launches -- every 4th of a plan, every one of a replan --
+            # so that they can stay on inside the timed region: ltimed of the llaunch launches)
+            avg_launch_s = lkms * 1e-3 / ltimed
+            achieved = (lvis / llaunch) * BYTES_PER_TILE_VISIT / avg_launch_s / 1e9
             traffic = None
             tj = os.path.join(ROOT, "profiles", "r1_traffic.json")
             if os.path.exists(tj) and args.algo == "FD" and size == 4096:
                 traffic = json.load(open(tj)).get("traffic_bytes_per_launch")   # rocprofv3 PMC, same command
             out["roofline"] = {
-                "bound": "hbm", "kernel": "k_relax<%s,LOWER>" % args.algo, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "bound": "hbm", "kernel": "k_relax<%s,LOWER,cursor> (the lowering kernel as launched by the plans)" % args.algo, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                "avg_launch_us": 1e3 * lkms / llaunch,
+                "avg_launch_us": 1e6 * avg_launch_s, "timed_launches": ltimed, "launches": llaunch,
                 "algorithmic_bytes_per_launch": lvis * BYTES_PER_TILE_VISIT / llaunch,
                 "tile_visits_per_launch": lvis / llaunch,
-                "kernel_time_share": kms * 1e-3 / dt,
+                "kernel_time_share": avg_launch_s * llaunch / dt,
                 "note": "latency-bound (dependent in-LDS sweeps along the wavefront), not bandwidth-bound: see DESIGN.md",
             }
         if not args.no_cpu_baseline and world == 1:   # the CPU baseline is reported at N = 1 only

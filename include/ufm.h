@@ -51,12 +51,14 @@ typedef struct ufm_stats {
     uint64_t elem_evals;       /* element RHS evaluations actually executed */
     uint32_t launches;         /* relax kernel launches in this step */
     uint32_t raise_launches;   /* of which in the invalidation phase */
-    float kernel_ms;           /* summed relax-kernel time (HIP events) if profiling is on, else 0 */
+    float kernel_ms;           /* relax-kernel time (HIP events) of the timed_launches launches; 0 unless profiling is on */
     uint64_t crit_sweeps;      /* profiling only: sum over launches of the slowest tile's sweep count */
     uint64_t raise_tile_visits; /* tile visits of the invalidation kernel (subset of tile_visits) */
     float raise_kernel_ms;     /* part of kernel_ms spent in the invalidation kernel */
     uint32_t queued_lower;     /* tiles still queued after the step (parked beyond the start's key): */
     uint32_t queued_raise;     /*   the counterpart of the reference's priority_queue.size() */
+    uint32_t timed_launches;   /* profiling: launches covered by kernel_ms (a sample: every 4th launch of a plan, */
+    uint32_t timed_raise_launches; /*   every launch of a replan); of which in the invalidation phase (raise_kernel_ms) */
 } ufm_stats;
 
 /* ---- lifetime: `PlannerT<OPT_LVL> planner{}` (e.g. Tests/Planners/FDSTAR/main.cpp:77) ---- */

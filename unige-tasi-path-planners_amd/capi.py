@@ -40,6 +40,8 @@ class Stats(C.Structure):
         ("raise_kernel_ms", C.c_float),
         ("queued_lower", C.c_uint32),
         ("queued_raise", C.c_uint32),
+        ("timed_launches", C.c_uint32),
+        ("timed_raise_launches", C.c_uint32),
     ]
 
     def as_dict(self):

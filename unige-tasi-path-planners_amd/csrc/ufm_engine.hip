@@ -1155,7 +1155,8 @@ struct Engine {
     int fetch_counters();
     int wait_published();
     int win_raise[6] = {3, 3, 3, 3, 3, 3}, win_lower[6] = {4, 4, 4, 4, 4, 4}, win_pos = 0;   // launches recent replans needed
-    int run_phase(int mode, float rbound, uint32_t *launches, float *kernel_ms);
+    int run_phase(int mode, float rbound, uint32_t *launches, float *kernel_ms, uint32_t *timed);
+    int profile_stride = 4;          // profiling: every n-th launch of a plan is bracketed by events
     int reset_queues();
     int read_bounds(float *bmax);
     int step(ufm_stats *out);
@@ -1384,32 +1385,35 @@ int Engine::launch_relax(int mode, float rbound, hipEvent_t e0, hipEvent_t e1) {
 // costs a few microseconds, a host round trip more).
 // A phase also ends when a launch released nothing: everything still queued lies beyond the bound
 // (the start's key) and stays queued for a later step.
-int Engine::run_phase(int mode, float rbound, uint32_t *launches, float *kernel_ms) {
+int Engine::run_phase(int mode, float rbound, uint32_t *launches, float *kernel_ms, uint32_t *timed) {
     const int q = (mode == MODE_LOWER) ? Q_LOWER : Q_RAISE;
     int batch = batch_fixed > 0 ? batch_fixed : 4;
     const long cap = 64L * (P.TX + P.TY) * T + 4096;   // generous bound on sweeps
     long total = 0;
     for (;;) {
+        int ns = 0;   // launches of this batch that are timed: a sample, the event packets cost ~4 us each
         for (int k = 0; k < batch; ++k) {
-            if (profiling) {
-                if (ev.size() < (size_t)(2 * (k + 1))) {
-                    hipEvent_t a, b2;
-                    HIPCHK(hipEventCreate(&a)); HIPCHK(hipEventCreate(&b2));
-                    ev.push_back(a); ev.push_back(b2);
+            const bool timed_k = profiling && ((total + k) % profile_stride == 0);
+            if (timed_k) {
+                while (ev.size() < (size_t)(2 * (ns + 1) + 4)) {   // ev[0..3] belong to the replan path
+                    hipEvent_t a;
+                    HIPCHK(hipEventCreate(&a));
+                    ev.push_back(a);
                 }
             }
-            launch_relax(mode, rbound, profiling ? ev[2 * k] : nullptr, profiling ? ev[2 * k + 1] : nullptr);
+            launch_relax(mode, rbound, timed_k ? ev[4 + 2 * ns] : nullptr, timed_k ? ev[4 + 2 * ns + 1] : nullptr);
+            if (timed_k) ++ns;
         }
         HIPCHK(hipGetLastError());
         *launches += (uint32_t)batch;
         total += batch;
         { int rc = fetch_counters(); if (rc != UFM_OK) return rc; }
-        if (profiling)
-            for (int k = 0; k < batch; ++k) {
-                float ms = 0;
-                HIPCHK(hipEventElapsedTime(&ms, ev[2 * k], ev[2 * k + 1]));
-                *kernel_ms += ms;
-            }
+        for (int k = 0; k < ns; ++k) {
+            float ms = 0;
+            HIPCHK(hipEventElapsedTime(&ms, ev[4 + 2 * k], ev[4 + 2 * k + 1]));
+            *kernel_ms += ms;
+        }
+        *timed += (uint32_t)ns;
         const int active = h_ctr->cnt[q][iter[q] % 3];
         last_active = active;
         if (active == 0) return UFM_OK;
@@ -1552,7 +1556,8 @@ int Engine::step(ufm_stats *out) {
         int nr = 1, nl = 1;
         for (int i = 0; i < 6; ++i) { nr = std::max(nr, win_raise[i] + batch_margin); nl = std::max(nl, win_lower[i] + batch_margin); }
         const int k0_raise = iter[Q_RAISE], k0_lower = iter[Q_LOWER];
-        const bool graphed = fused && use_graph && !profiling && nr < 250 && nl < 250;
+        if (profiling) while (ev.size() < 4) { hipEvent_t a; HIPCHK(hipEventCreate(&a)); ev.push_back(a); }
+        const bool graphed = fused && use_graph && nr < 250 && nl < 250;
         if (graphed) {
             rb.k_raise = iter[Q_RAISE]; rb.band = band;
             hipGraphExec_t ge = nullptr;
@@ -1614,6 +1619,8 @@ int Engine::step(ufm_stats *out) {
         updated += h_ctr->updated;
         st.raise_launches += (uint32_t)nr;
         st.launches += (uint32_t)(nr + nl);
+        // (launches replayed from the graph are not event-timed: HIP cannot read events recorded by graph nodes)
+        if (profiling && !graphed) { st.timed_launches += (uint32_t)(nr + nl); st.timed_raise_launches += (uint32_t)nr; }
         fast_done = h_ctr->done != 0;
         // launches the batches actually needed (for the next steps' batch sizes); a batch that was
         // too short costs a host round trip and the adaptive loop, so err on the long side after one
@@ -1677,9 +1684,11 @@ int Engine::step(ufm_stats *out) {
                 uint32_t rl = 0;
                 float rk = 0.0f;
                 k_unpark<<<1, 1024, 0, stream>>>(P, Q_RAISE, iter[Q_RAISE], rbound);
-                int rc = run_phase(MODE_RAISE, rbound, &rl, &rk);
+                uint32_t rt = 0;
+                int rc = run_phase(MODE_RAISE, rbound, &rl, &rk, &rt);
                 if (rc != UFM_OK) return rc;
                 st.kernel_ms += rk; st.raise_kernel_ms += rk;
+                st.timed_launches += rt; st.timed_raise_launches += rt;
                 st.raise_launches += rl;
                 st.launches += rl;
                 // everything invalidation touched must be re-lowered
@@ -1688,7 +1697,7 @@ int Engine::step(ufm_stats *out) {
             const auto tb = std::chrono::steady_clock::now();
             uint32_t ll = 0;
             k_unpark<<<1, 1024, 0, stream>>>(P, Q_LOWER, iter[Q_LOWER], INFINITY);
-            int rc = run_phase(MODE_LOWER, INFINITY, &ll, &st.kernel_ms);
+            int rc = run_phase(MODE_LOWER, INFINITY, &ll, &st.kernel_ms, &st.timed_launches);
             if (rc != UFM_OK) return rc;
             st.launches += ll;
             bool again = false;
@@ -2023,6 +2032,7 @@ int ufm_set_param(ufm_t *p, const char *name, double value) {
     else if (!std::strcmp(name, "graph")) e->use_graph = value != 0;
     else if (!std::strcmp(name, "batch_margin")) e->batch_margin = (int)value;
     else if (!std::strcmp(name, "tail_grid")) e->tail_grid = value < 1 ? 1 : (int)value;
+    else if (!std::strcmp(name, "profile_stride")) e->profile_stride = value < 1 ? 1 : (int)value;
     else if (!std::strcmp(name, "focused")) e->focused = value != 0.0;
     else if (!std::strcmp(name, "dynamic")) e->dynamic_mode = value != 0.0;
     else return UFM_ERR_INVALID;
