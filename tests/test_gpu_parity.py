@@ -334,6 +334,79 @@ def test_patches_accumulate_until_the_next_step():
     g.close(); f.close()
 
 
+@pytest.mark.parametrize("algo,lvl", [("FD", 1), ("DFM", 1)])
+def test_replan_submission_variants_agree(algo, lvl):
+    """A replan is submitted as one captured graph of fused control kernels whose result the host
+    picks up from host-coherent memory.  Each of the three mechanisms can be switched off; fields
+    (focused mode, below the start key: against the oracle; full field: bitwise between variants in
+    full-field mode), num_nodes_updated and num_nodes_expanded must not depend on them.  Includes a
+    step with 6 pending patches (more than the fused kernel takes) and one with a 70x70 patch
+    (larger than the single-workgroup patch kernel takes)."""
+    width = length = 208
+    seed = 31
+    cost = ufm_amd.synth.cost_map(seed, width, length)
+    start, goal = ufm_amd.synth.start_goal(width, length)
+    script = list(ufm_amd.synth.replan_script(seed, width, length, n_patches=12))
+    rng = np.random.default_rng(3)
+    big = rng.integers(1, 200, (70, 70), dtype=np.uint8)
+    variants = [dict(), dict(graph=0), dict(graph=0, fuse_control=0), dict(graph=0, fuse_control=0, spin_wait=0), dict(spin_wait=0)]
+    results = []
+    for full in (1, 0):
+        results.clear()
+        for v in variants:
+            p = ufm_amd.Planner(ALGOS[algo], lvl)
+            p.set_param("focused", 0 if full else 1)
+            for name, val in v.items():
+                p.set_param(name, val)
+            p.set_occupancy_threshold(1); p.set_map(cost); p.set_start(*start); p.set_goal(*goal)
+            assert p.step() == 0
+            log = []
+            for k, s, top, left, patch in script:
+                if k == 5:        # six rectangles before one step
+                    for j in range(5):
+                        p.patch_map(patch[: 8 + j, : 9 + j].copy(), min(top + 3 * j, length - 40), min(left + 5 * j, width - 40))
+                if k == 8:        # a patch of 70 x 70 cells
+                    p.patch_map(big, 60, 70)
+                p.patch_map(patch, top, left)
+                p.set_start(*s)
+                assert p.step() == 0
+                log.append((p.num_nodes_updated, p.num_nodes_expanded if (full and algo != "DFM") else 0))
+            results.append((p.g(), log, p.read_map(width, length)))
+            p.close()
+        for g, log, m in results[1:]:
+            assert log == results[0][1]
+            assert np.array_equal(m, results[0][2])
+            if full and algo != "DFM":
+                assert np.array_equal(g, results[0][0])
+            elif full:   # DFM's float fixed point depends on the relaxation order at the ulp level (DESIGN.md section 6)
+                r0 = results[0][0]
+                fin = np.isfinite(r0)
+                assert np.array_equal(fin, np.isfinite(g))
+                assert np.all(np.abs(g[fin].astype(np.float64) - r0[fin]) <= 4e-6 * r0[fin] + 1e-30)
+    # focused mode (the last loop): against the oracle, below the start's key
+    o = __import__("oracle_py").OraclePlanner(ALGOS[algo], lvl, False)
+    o.reset(); o.set_occupancy_threshold(1); o.set_map(cost); o.set_start(*start); o.set_goal(*goal)
+    assert o.step() == 0
+    for k, s, top, left, patch in script:
+        if k == 5:
+            for j in range(5):
+                o.patch_map(patch[: 8 + j, : 9 + j].copy(), min(top + 3 * j, length - 40), min(left + 5 * j, width - 40))
+                o.set_start(*s); o.step()      # the reference keeps only the last patch's change list: step per patch
+        if k == 8:
+            o.patch_map(big, 60, 70); o.set_start(*s); o.step()
+        o.patch_map(patch, top, left)
+        o.set_start(*s)
+        assert o.step() == 0
+    mask = o.trusted_mask(below_start_key=True)
+    og = o.g()
+    for g, log, m in results:
+        a, b = g[mask], og[mask]
+        if algo == "DFM":
+            assert np.all(np.abs(a.astype(np.float64) - b) <= 2e-6 * b + 1e-30)
+        else:
+            assert np.array_equal(a, b)
+
+
 def test_headline_size_4096_against_oracle_and_properties():
     """BASELINE.json's headline configuration (Field D* level 1, 4096x4096): the full plan and a few
     replans are compared with the oracle bit for bit on the set a planner honouring end_condition
