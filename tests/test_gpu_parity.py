@@ -440,3 +440,78 @@ def test_headline_size_4096_against_oracle_and_properties():
     assert g.step() == 0
     assert g.num_nodes_expanded == 0 and np.array_equal(before, g.g())
     g.close(); u.close()
+
+
+def test_config5_8192_heuristic_keys_moving_start_properties():
+    """BASELINE.json config 5 (Field D* 8192x8192, moving start, heuristic keys re-ordered per move;
+    this GPU's replica).  The oracle needs minutes at this size, so the check is by properties: a
+    focused engine with heuristic keys equals a full-field engine on every node whose key lies below
+    the start's key, after the plan and after each move; the goal stays 0; an idle step changes
+    nothing."""
+    size, seed = 8192, 42
+    cost = ufm_amd.synth.cost_map(seed, size, size)
+    hm = float(cost.min())
+    start, goal = ufm_amd.synth.start_goal(size, size)
+    g = ufm_amd.Planner(ufm_amd.ALGO_FD, 1, True)
+    u = ufm_amd.Planner(ufm_amd.ALGO_FD, 1, False)
+    u.set_param("focused", 0)
+    for p in (g, u):
+        p.set_occupancy_threshold(1); p.set_heuristic_multiplier(hm); p.set_map(cost); p.set_start(*start); p.set_goal(*goal)
+        assert p.step() == 0
+    xs = np.arange(size + 1, dtype=np.float32)
+
+    def agree(s):
+        gf, gu = g.g(), u.g()
+        assert gf[int(goal[0]), int(goal[1])] == 0.0
+        sx, sy = int(round(s[0])), int(round(s[1]))
+        dist = np.hypot(xs[:, None] - np.float32(s[0]), xs[None, :] - np.float32(s[1])).astype(np.float32)
+        corners = [(sx + a, sy + b) for a in (0, 1) for b in (0, 1)]
+        key = max(gu[c] + np.float32(hm) * dist[c] for c in corners)
+        m = (gu + np.float32(hm) * dist) < key
+        assert int(m.sum()) > 1000
+        assert np.array_equal(gf[m], gu[m]), "focused/heuristic engine differs from the full field below the start's key"
+        return int(m.sum())
+
+    n0 = agree(start)
+    assert n0 < (size + 1) ** 2            # the heuristic did leave part of the map alone
+    for k, s, top, left, patch in ufm_amd.synth.replan_script(seed, size, size, n_patches=3):
+        for p in (g, u):
+            p.patch_map(patch, top, left)
+            p.set_heuristic_multiplier(hm)
+            p.set_start(*s)
+            assert p.step() == 0
+        agree(s)
+    before = g.g()
+    g.set_start(*s)
+    assert g.step() == 0 and g.num_nodes_expanded == 0
+    assert np.array_equal(before, g.g())
+    g.close(); u.close()
+
+
+def test_config4_batch_of_8_maps_2048_dfm():
+    """BASELINE.json config 4, one GPU's share: 8 independent 2048x2048 MS-DFM maps planned in one
+    batch.  Map 5 equals a planner of its own within DFM's tolerance, every map reaches its start,
+    and one launch extracts all eight paths."""
+    n, size = 8, 2048
+    b = ufm_amd.BatchPlanner(n, ufm_amd.ALGO_DFM, 1)
+    b.set_occupancy_threshold(1.0)
+    start, goal = ufm_amd.synth.start_goal(size, size)
+    costs = []
+    for m in range(n):
+        c = ufm_amd.synth.cost_map(1000 + m, size, size)
+        costs.append(c)
+        b.set_map(m, c); b.set_start(m, *start); b.set_goal(m, *goal)
+    assert b.step() == 0
+    p = ufm_amd.Planner(ufm_amd.ALGO_DFM, 1)
+    p.set_occupancy_threshold(1.0); p.set_map(costs[5]); p.set_start(*start); p.set_goal(*goal)
+    assert p.step() == 0
+    gb, gp = b.read_field(5), p.g()
+    key = gp[int(start[0]), int(start[1])]
+    m = gp < key
+    assert int(m.sum()) > 3_000_000
+    assert np.all(np.abs(gb[m].astype(np.float64) - gp[m]) <= 4e-6 * gp[m] + 1e-30)
+    for k in range(n):
+        assert np.isfinite(b.read_field(k)[int(start[0]), int(start[1])])
+    paths = b.extract_paths(max_steps=20)
+    assert len(paths) == n and all(len(pt[0]) >= 2 and pt[2] > 0 for pt in paths)
+    b.close(); p.close()
