@@ -77,6 +77,26 @@ def trace_report():
             print("      missed examples (sweeps, seen, hint, ninf0, ninf1): " + str([(int(sw[i]), int(seen[i]), int(hint[i]), int(n0[i]), int(n1[i])) for i in np.nonzero(missed)[0][:8]]))
 
 
+L.ufm_debug_wtrace.argtypes = [C.c_void_p, C.c_void_p]
+
+
+def wave_report():
+    buf = np.zeros(16 * 256 * 2, np.uint64)
+    cnt = np.zeros(16, np.uint32)
+    if L.ufm_debug_wtrace(buf.ctypes.data, cnt.ctypes.data) != 0 or cnt.max() == 0:
+        return
+    r = buf.reshape(16, 256, 2)
+    t0 = min(int(r[w, 0, 1]) for w in range(16) if cnt[w])
+    names = {0: "start", 1: "burst", 2: "done", 3: "idle", 4: "woken", 5: "vote"}
+    print("  per-wave timeline of one visit (us since visit start; burst(bits) ... done(total sweeps so far)):")
+    for w in range(16):
+        ev = []
+        for i in range(min(int(cnt[w]), 256)):
+            ty, val, t = int(r[w, i, 0]) >> 32, int(r[w, i, 0]) & 0xFFFFFFFF, (int(r[w, i, 1]) - t0) / 100.0
+            ev.append("%s%s@%.2f" % (names.get(ty, "?"), "(%d)" % val if ty in (0, 2) else "", t))
+        print("   wave %2d (patch %d,%d): %s" % (w, w >> 2, w & 3, " ".join(ev)))
+
+
 for rep in range(2):
     p = ufm_amd.Planner(*algo)
     p.set_profiling(1)
@@ -88,6 +108,8 @@ for rep in range(2):
     assert p.step() == 0
     report("plan", p)
     trace_report()
+    if rep == 1:
+        wave_report()
     if a.replans and rep == 1:
         for k, s, top, left, patch in ufm_amd.synth.replan_script(7, a.size, a.size, n_patches=a.replans):
             p.patch_map(patch, top, left)

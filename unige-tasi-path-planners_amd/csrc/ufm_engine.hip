@@ -52,7 +52,7 @@ constexpr int NTHR = 1024;     // 16 waves; four lanes per node, each wave owns 
 #define UFM_LPT 1              // longest-expected-first hand-out of the ready list
 #endif
 #ifndef UFM_LONG_SWEEPS
-#define UFM_LONG_SWEEPS 12     // a visit that took at least this many sweeps per wave counts as long
+#define UFM_LONG_SWEEPS 8      // a visit that took at least this many sweeps per wave counts as long
 #endif
 #ifndef UFM_IDLE_SLEEP
 #define UFM_IDLE_SLEEP 4
@@ -200,6 +200,12 @@ __device__ unsigned long long g_tdiag[64];
 #endif
 __device__ unsigned long long g_trace[4 * 16384];
 __device__ unsigned int g_ntrace;
+// per-wave timeline of ONE tile visit (the first long-list visit of workgroup 0 in launch UFM_TRACE_K0):
+// records {type, t, value}; 1 burst start (wake bits), 2 burst end (sweeps in it), 3 idle, 4 woken, 5 vote
+__device__ unsigned long long g_wtrace[16 * 256 * 2];
+__device__ unsigned int g_nw[16];
+#define UFM_WREC(type, val) do { if (wtrace_on && lane == 0) { const unsigned int i_ = g_nw[w]++; if (i_ < 256) { \
+    g_wtrace[(w * 256 + i_) * 2] = ((unsigned long long)(type) << 32) | (unsigned int)(val); g_wtrace[(w * 256 + i_) * 2 + 1] = wall_clock64(); } } } while (0)
 __device__ __forceinline__ void trace_rec(int k, int kind, unsigned long long t0, unsigned long long t1, long long sw) {
     if (k < UFM_TRACE_K0 || k >= UFM_TRACE_K0 + 8) return;
     const unsigned int i = atomicAdd(&g_ntrace, 1u);
@@ -210,6 +216,7 @@ __device__ __forceinline__ void trace_rec(int k, int kind, unsigned long long t0
 #define UFM_TICK(v) const unsigned long long v = wall_clock64()
 #else
 #define UFM_TICK(v)
+#define UFM_WREC(type, val)
 #endif
 
 // ---- update operators -------------------------------------------------------
@@ -548,12 +555,17 @@ __global__ __launch_bounds__(NTHR) void k_relax(DevParams P, int k_arg, float de
         int tot = 0;
         const bool lax = (ALGO == UFM_ALGO_DFM) && (s_misc[1] > 16);
         bool conv = false;
+#ifdef UFM_TIMING
+        const bool wtrace_on = DYN && MODE == MODE_LOWER && k == UFM_TRACE_K0 && i == 0;
+        UFM_WREC(0, s_misc[1]);
+#endif
         for (;;) {
             int bits = 0;
             if (lane == 0) bits = atomicExch(&s_wake[w], 0);
             bits = __builtin_amdgcn_readfirstlane(bits);
             bool vote = __hip_atomic_load(&s_giveup, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != 0;
             if (bits && !vote) {
+                UFM_WREC(1, bits);
 #pragma unroll
                 for (int j = 0; j < PPW; ++j) {
                     if (!(bits & (1 << j))) continue;    // wave-uniform
@@ -594,6 +606,7 @@ __global__ __launch_bounds__(NTHR) void k_relax(DevParams P, int k_arg, float de
                     if (again && lane == 0)              // burst cap: leave the rest to the next take
                         __hip_atomic_fetch_or(&s_wake[w], 1 << j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 }
+                UFM_WREC(2, tot);
                 if (tot >= PPW * max_sweeps && lane == 0)  // give up this visit; the tile is re-queued
                     __hip_atomic_store(&s_giveup, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 continue;
@@ -601,12 +614,14 @@ __global__ __launch_bounds__(NTHR) void k_relax(DevParams P, int k_arg, float de
             if (!vote) {                                 // nothing to do: idle until woken or all idle
                 if (bits && lane == 0) __hip_atomic_fetch_or(&s_wake[w], bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 if (lane == 0) atomicAdd(&s_idle, 1);
+                UFM_WREC(3, 0);
                 for (;;) {
                     __builtin_amdgcn_s_sleep(UFM_IDLE_SLEEP);
                     if (__hip_atomic_load(&s_idle, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >= 16 ||
                         __hip_atomic_load(&s_giveup, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != 0) { vote = true; break; }
                     if (__hip_atomic_load(&s_wake[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != 0) {
                         if (lane == 0) atomicSub(&s_idle, 1);
+                        UFM_WREC(4, 0);
                         break;
                     }
                 }
@@ -615,6 +630,7 @@ __global__ __launch_bounds__(NTHR) void k_relax(DevParams P, int k_arg, float de
                 __hip_atomic_fetch_or(&s_wake[w], bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // put back what was taken
             }
             // vote: everybody arrives first, then the wake bits are stable
+            UFM_WREC(5, 0);
             __syncthreads();
             const int work = __syncthreads_or(__hip_atomic_load(&s_wake[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != 0);
             const int gave_up = __hip_atomic_load(&s_giveup, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -1956,6 +1972,13 @@ int ufm_debug_trace(unsigned long long *out, int cap) {     // returns the numbe
     const unsigned int z = 0;
     hipMemcpyToSymbol(HIP_SYMBOL(g_ntrace), &z, sizeof(z));
     return (int)n;
+}
+int ufm_debug_wtrace(unsigned long long *out, unsigned int *counts) {
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_wtrace), sizeof(unsigned long long) * 16 * 256 * 2) != hipSuccess) return UFM_ERR_HIP_BASE;
+    if (hipMemcpyFromSymbol(counts, HIP_SYMBOL(g_nw), sizeof(unsigned int) * 16) != hipSuccess) return UFM_ERR_HIP_BASE;
+    unsigned int z[16] = {};
+    hipMemcpyToSymbol(HIP_SYMBOL(g_nw), z, sizeof(z));
+    return UFM_OK;
 }
 int ufm_debug_tdiag(unsigned long long *out, int reset) {
     if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(g_tdiag), sizeof(unsigned long long) * 64) != hipSuccess) return UFM_ERR_HIP_BASE;
