@@ -6,13 +6,16 @@
  * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may
  * load this library.  The product path (libufm.so, HIP) never links it.
  *
- * PARITY PINNING STATUS: "parity unpinned" in the strict sense -- the
- * reference ships no golden vectors / known-answer tests for this path and
- * cannot be compiled in this image (its three header-only dependencies are
- * un-vendored empty submodules; writing stand-ins for them is not allowed).
- * The restatement follows the reference sources line by line (citations in
- * ufm_oracle.c) and is cross-checked against the known answers SURVEY.md
- * App. E recorded for the reference's own `noise-trap` bitmap.
+ * PARITY PINNING STATUS: pinned on the only outputs of the reference that exist -- the known
+ * answers SURVEY.md App. E recorded from the reference compiled there for its own `noise-trap`
+ * bitmap: expansions, map size, sum of G over the consistent set and G(start) for all seven
+ * planner variants, and points / total_cost / total_dist of the extracted path for DFM, SG and FD.
+ * This restatement reproduces every one of them (tests/test_oracle.py).  Beyond those it is
+ * "parity unpinned": the reference ships no golden vectors / known-answer tests for this path and
+ * cannot be compiled in this image (its three header-only dependencies are un-vendored empty
+ * submodules; writing stand-ins for them is not allowed), so there is no oracle/_ref build.
+ * The restatement follows the reference sources function by function (citations in
+ * ufm_oracle.c / ufm_path_oracle.c).
  */
 #ifndef UFM_ORACLE_H
 #define UFM_ORACLE_H
