@@ -1128,6 +1128,7 @@ struct Engine {
     bool fuse_control = true;        // replans: fused control kernels (k_replan_begin / _raise_to_lower / _end)
     bool use_graph = true;           // replans: the whole submission replayed as one captured hipGraph
     int batch_margin = 1;            // replans: launches per phase = most that the last 6 replans needed + this
+    float raise_margin = 0.25f;      // invalidation bound = start key + this many ordering bands (a miss costs a second round)
     ReplanJob *h_job = nullptr;      // host-coherent pinned: per-replan inputs of the graph's first node
     struct GraphSig { DevParams P; float band, delta; int max_iters, grid; };
     GraphSig graph_sig{};
@@ -1547,7 +1548,8 @@ int Engine::step(ufm_stats *out) {
     uint64_t updated = 0;
     bool have_seeds = false;
     bool fast_done = false;
-    const float band = (delta_abs >= 0.0f ? delta_abs : delta_scale * T * mean_cost);
+    // margin of the invalidation bound above the start's current key (the key may rise through the patch)
+    const float band = raise_margin * (delta_abs >= 0.0f ? delta_abs : delta_scale * T * mean_cost);
     if (n_upd > 0 || n_init > 0) {
         if (!single) HIPCHK(hipMemcpyAsync(P.consume, consume, sizeof(int) * nmaps, hipMemcpyHostToDevice, stream));
         // consume pending patch rectangles of the participating maps
@@ -2054,6 +2056,7 @@ int ufm_set_param(ufm_t *p, const char *name, double value) {
     else if (!std::strcmp(name, "fuse_control")) e->fuse_control = value != 0;
     else if (!std::strcmp(name, "graph")) e->use_graph = value != 0;
     else if (!std::strcmp(name, "batch_margin")) e->batch_margin = (int)value;
+    else if (!std::strcmp(name, "raise_margin")) e->raise_margin = (float)value;
     else if (!std::strcmp(name, "tail_grid")) e->tail_grid = value < 1 ? 1 : (int)value;
     else if (!std::strcmp(name, "profile_stride")) e->profile_stride = value < 1 ? 1 : (int)value;
     else if (!std::strcmp(name, "focused")) e->focused = value != 0.0;
