@@ -45,6 +45,9 @@ constexpr int PT = T / 4;      // 4x4-node patches per tile side
 constexpr int PR = PT / 4;     // patches per wave per side (the 16 waves form a 4x4 grid)
 constexpr int PPW = PR * PR;   // patches per wave: 4 (T = 32) or 1 (T = 16)
 constexpr int NTHR = 1024;     // 16 waves; four lanes per node, each wave owns PPW 4x4-node patches
+#ifndef UFM_RELAX_WAVES
+#define UFM_RELAX_WAVES 4      // waves per SIMD the relax kernel is compiled for (4: one 1024-thread workgroup per CU)
+#endif
 #ifndef UFM_CAUSAL_FILTER
 #define UFM_CAUSAL_FILTER 1    // do not wake a neighbour tile that a changed border value cannot influence
 #endif
@@ -380,7 +383,7 @@ __device__ __forceinline__ float cell_cost(const DevParams &P, const uint8_t *cm
 // DYN: the tiles come from the ready list k_triage built (taken through an atomic cursor: perfect
 // balance, used while the queue is long); !DYN: triage fused as described above (short queues).
 template <int ALGO, int MODE, bool DYN>
-__global__ __launch_bounds__(NTHR) void k_relax(DevParams P, int k_arg, float delta, float rbound, int max_sweeps) {
+__global__ __launch_bounds__(NTHR, UFM_RELAX_WAVES) void k_relax(DevParams P, int k_arg, float delta, float rbound, int max_sweeps) {
     __shared__ float Gs[(T + 2) * GP];
     __shared__ float Cs[(T + 1) * CP];
     __shared__ int s_wake[16];  // per wave: bit j = patch j of the wave has new inputs (PPW bits)
@@ -1782,6 +1785,10 @@ int engine_create(Engine **out, int n_maps, int algo, int opt_lvl, int use_heuri
     Engine *e = new (std::nothrow) Engine();
     if (!e) return UFM_ERR_NOMEM;
     e->algo = algo; e->opt_lvl = opt_lvl; e->heur = use_heuristic; e->device = device_id; e->nmaps = n_maps;
+    // scheduling defaults per planner family (tools/sweep.py, 4096^2): DFM's two-stencil operator needs about
+    // twice the sweeps per tile; a wider band and an earlier re-queue suit it better (plan 60 -> 52 ms)
+    // -- for a single map; a batch is throughput-bound and keeps the less redundant setting (8 x 2048^2: 484 vs 476 M cells/s)
+    if (algo == UFM_ALGO_DFM && n_maps == 1) { e->delta_scale = 2.5f; e->max_iters = 16; }
     e->maps.resize(n_maps);
     hipDeviceProp_t prop;
     HIPCHK(hipGetDeviceProperties(&prop, device_id));
