@@ -108,8 +108,15 @@ def main():
     planner.set_profiling(not args.no_profile)
 
     ep = ufm_amd.episode
-    stream = ep.PatchStream(d_patches if rank == 0 else None, d_recv, dist=dist, rank=rank,
-                            sync=lambda: torch.cuda.current_stream().synchronize())
+    # the broadcast patch becomes visible to the engine by a stream dependency (the engine's stream
+    # waits for torch's, on the GPU), not by blocking the host after every collective
+    try:
+        eng_stream = torch.cuda.ExternalStream(planner.stream_ptr(), device=dev)
+        patch_ready = lambda: eng_stream.wait_stream(torch.cuda.current_stream())
+        patch_ready()
+    except Exception:   # no external-stream support in this torch build: block the host instead
+        patch_ready = lambda: torch.cuda.current_stream().synchronize()
+    stream = ep.PatchStream(d_patches if rank == 0 else None, d_recv, dist=dist, rank=rank, sync=patch_ready)
     meta = [(k, s, top, left) for (k, s, top, left, _) in script]
 
     def step_stats(p):
@@ -140,6 +147,17 @@ def main():
     dt, per_step = ep.timed_episodes(run_one, args.steps, args.warmup, barrier)
     tot = [sum(d[k] for d in per_step) for k in ("cells", "visits", "launches", "kernel_ms", "evals")]
     low = [sum(d[k] for d in per_step) for k in ("lower_visits", "lower_launches", "lower_kernel_ms", "lower_timed")]
+
+    # self-check of the patch path (outside the timed region): every rank's raster must now be its own
+    # map with all the broadcast patches applied -- a collective that delivered late or wrong data fails here
+    expect = cost.copy()
+    for (_k, _s, top, left, patch) in script:
+        expect[top:top + patch.shape[0], left:left + patch.shape[1]] = patch
+    got = planner.read_map(size, size)
+    if not np.array_equal(got, expect):
+        bad = np.argwhere(got != expect)
+        raise RuntimeError("rank %d: raster on the device differs from map + patches in %d cells, first at %r (device %d, expected %d)" % (
+            rank, len(bad), tuple(bad[0]), got[tuple(bad[0])], expect[tuple(bad[0])]))
 
     cells, visits, launches, kms, evals = tot
     if dist is not None:

@@ -183,6 +183,10 @@ class Planner:
     def set_param(self, name, value):
         _chk(self.L.ufm_set_param(self.h, name.encode(), float(value)), "ufm_set_param")
 
+    def stream_ptr(self):
+        """hipStream_t the engine's kernels run on (e.g. for torch.cuda.ExternalStream)"""
+        return int(self.L.ufm_stream(self.h) or 0)
+
     def set_profiling(self, on):
         _chk(self.L.ufm_set_profiling(self.h, int(on)), "ufm_set_profiling")
 

@@ -55,7 +55,9 @@ def cost_map(seed, width, length, obstacles=True):
         nx = (np.abs(xi - sx) <= 16)[:, None] & (np.abs(yi - sy) <= 16)[None, :]
         ng = (np.abs(xi - gx) <= 16)[:, None] & (np.abs(yi - gy) <= 16)[None, :]
         cost[obs & ~(nx | ng)] = 255
-    return cost
+    # C order: fancy indexing above leaves a column-major array, and consumers that hand out the raw
+    # buffer (torch.from_numpy(...).data_ptr()) would see the transposed map
+    return np.ascontiguousarray(cost)
 
 
 def replan_script(seed, width, length, n_patches=100, size=31, stride=5):
