@@ -33,9 +33,9 @@ def test_planner_process_builds_and_prints_usage():
 class Sim:
     """simulator end of the pipes (run_simulator.py:38-103)"""
 
-    def __init__(self, to_planner, from_planner):
-        self.o = open(to_planner, "wb")        # same open order as run_test.py:92-93
-        self.i = open(from_planner, "rb")
+    def __init__(self, to_planner, from_planner, alive):
+        pipes = ufm_amd.harness.Pipes(to_planner, from_planner, alive=alive)   # does not hang if the planner died
+        self.o, self.i = pipes.o, pipes.i
 
     def send(self, fmt, *v):
         self.o.write(struct.pack("<" + fmt, *v))
@@ -75,7 +75,7 @@ def test_simulator_drives_the_planner_process(tmp_path, algo, lvl, heur, tof, ar
         cmd = [link, "--max-moves", str(moves), a, b]
     proc = subprocess.Popen(cmd, stdout=subprocess.DEVNULL)
     try:
-        sim = Sim(a, b)
+        sim = Sim(a, b, alive=lambda: proc.poll() is None)
         assert sim.recv("b") == (0,)
         sim.send("b", 0)
         sim.send("ii", width, length)

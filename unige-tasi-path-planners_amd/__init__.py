@@ -14,3 +14,4 @@ from .capi import (  # noqa: F401
 from . import capi  # noqa: F401
 from . import synth  # noqa: F401
 from . import episode  # noqa: F401
+from . import harness  # noqa: F401
