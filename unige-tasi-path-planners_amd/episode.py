@@ -23,13 +23,13 @@ class PatchStream:
     def fetch(self, i):
         if self.dist is None:
             return self.patches[i]
-        if self.rank == 0:
-            self.recv.copy_(self.patches[i])
-        self.dist.broadcast(self.recv, src=0)
+        # rank 0 sends straight from its patch store (no staging copy); the others receive into `recv`
+        buf = self.patches[i] if self.rank == 0 else self.recv
+        self.dist.broadcast(buf, src=0)
         self.broadcasts += 1
         if self.sync is not None:
             self.sync()
-        return self.recv
+        return buf
 
 
 def run_episode(planner, set_map, start, goal, script, stream, apply_patch, read_stats):
