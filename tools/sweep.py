@@ -14,13 +14,17 @@ ap.add_argument("--max-iters", default="128")
 ap.add_argument("--reps", type=int, default=2)
 ap.add_argument("--profile", type=int, default=0)
 ap.add_argument("--param", action="append", default=[], help="name=value for ufm_set_param")
+ap.add_argument("--heuristic", type=int, default=0, help="heuristic keys with hm = min cost (BASELINE config 5)")
+ap.add_argument("--seed", type=int, default=7)
 a = ap.parse_args()
 algo = {"FD": 0, "SG": 1, "DFM": 2}[a.algo]
-size, seed = a.size, 7
+size, seed = a.size, a.seed
 cost = ufm_amd.synth.cost_map(seed, size, size)
 start, goal = ufm_amd.synth.start_goal(size, size)
 script = list(ufm_amd.synth.replan_script(seed, size, size, n_patches=a.patches))
-p = ufm_amd.Planner(algo, 1 if algo != 1 else 2)
+p = ufm_amd.Planner(algo, 1 if algo != 1 else 2, bool(a.heuristic))
+if a.heuristic:
+    p.set_heuristic_multiplier(float(cost.min()))
 p.set_occupancy_threshold(1)
 p.set_profiling(a.profile)
 for kv in a.param:
