@@ -119,6 +119,15 @@ def main():
     stream = ep.PatchStream(d_patches if rank == 0 else None, d_recv, dist=dist, rank=rank, sync=patch_ready)
     meta = [(k, s, top, left) for (k, s, top, left, _) in script]
 
+    ptr_cache = {}
+
+    def apply_patch(p, buf, top, left):
+        key = id(buf)
+        ptr = ptr_cache.get(key)
+        if ptr is None:
+            ptr = ptr_cache[key] = buf.data_ptr()      # the per-patch views live as long as the stream
+        p.patch_map_device(ptr, top, left, psz, psz)
+
     def step_stats(p):
         st = p.stats
         d = {"cells": st.expanded, "visits": st.tile_visits, "launches": st.launches, "kernel_ms": st.kernel_ms, "evals": st.elem_evals,
@@ -135,7 +144,7 @@ def main():
             planner,
             set_map=lambda p: p.set_map_device(d_cost.data_ptr(), size, size),
             start=start, goal=goal, script=meta, stream=stream,
-            apply_patch=lambda p, buf, top, left: p.patch_map_device(buf.data_ptr(), top, left, psz, psz),
+            apply_patch=apply_patch,
             read_stats=step_stats)
 
     def barrier():

@@ -10,11 +10,12 @@ import time
 
 
 class PatchStream:
-    """Rank 0 holds all patches; `fetch(i)` returns patch i on every rank."""
+    """Rank 0 holds all patches; `fetch(i)` returns patch i on every rank.  Per-patch views are made
+    once (slicing a tensor costs microseconds, a replan a few hundred)."""
 
     def __init__(self, patches, recv_buffer, dist=None, rank=0, sync=None):
-        self.patches = patches          # rank 0: sequence of patch tensors; other ranks: None / unused
-        self.recv = recv_buffer         # tensor every rank receives into
+        self.patches = None if patches is None else [patches[i] for i in range(len(patches))]
+        self.recv = recv_buffer         # tensor every other rank receives into
         self.dist = dist
         self.rank = rank
         self.sync = sync                # callable making the broadcast result visible to the consumer
