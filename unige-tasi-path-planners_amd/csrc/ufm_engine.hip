@@ -727,6 +727,16 @@ __global__ __launch_bounds__(NTHR, UFM_RELAX_WAVES) void k_relax(DevParams P, in
     }
 }
 
+// index for the lanes with `pred` from one atomicAdd per wave (all lanes of the wave must call)
+__device__ __forceinline__ int wave_slot(bool pred, int *counter) {
+    const unsigned long long mk = __ballot(pred);
+    if (!mk) return 0;
+    const int lane = threadIdx.x & 63, leader = __ffsll((long long)mk) - 1;
+    int base = 0;
+    if (lane == leader) base = atomicAdd(counter, __popcll(mk));
+    base = __shfl(base, leader);
+    return base + __popcll(mk & ((1ull << lane) - 1ull));
+}
 // Vectorised triage for long queues: one thread per queued tile decides "release now" (append to
 // the ready list of the following relax launch) or "carry over" (same list ring as k_relax).
 template <int MODE>
@@ -739,30 +749,63 @@ __global__ void k_triage(DevParams P, int k, float delta, float rbound) {
     int *queued = P.queued + (size_t)(Q * 2 + pc) * P.NT;
     const float theta = __int_as_float(P.ctr->lmin[Q][r]) + delta;
     const float rb = (rbound < 0.0f) ? P.ctr->rbound : rbound;
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-        const int gt = cand[i];
-        const int pbits = prio[gt];
+    // start keys of the first 64 maps once per workgroup: their loads (start elements -> G) then run
+    // beside the list -> priority chain instead of behind it
+    __shared__ float s_B[64];
+    if (MODE == MODE_LOWER && P.focused) {
+        if (threadIdx.x < 64 && (int)threadIdx.x < P.nmaps) s_B[threadIdx.x] = start_bound(P, threadIdx.x);
+        __syncthreads();
+    }
+    // One list entry per thread; every append goes through one atomic per wave (ballot + popcount):
+    // thousands of same-address atomics -- list cursors, the list minimum -- were most of this kernel
+    for (int base = blockIdx.x * blockDim.x; base < n; base += gridDim.x * blockDim.x) {
+        const int i = base + threadIdx.x;
+        const bool valid = i < n;
+        const int gt = valid ? cand[i] : 0;
+        const int pbits = valid ? prio[gt] : INFBITS;
         const int m = gt / P.NTm, t = gt - m * P.NTm;
-        bool release, parked = false;
-        if (MODE == MODE_LOWER) {
-            const float B = P.focused ? start_bound(P, m) : INFINITY;
-            const float hd = P.focused ? tile_heuristic(P, m, t / P.TY, t % P.TY) : 0.0f;
-            parked = !(__int_as_float(pbits) + hd < B || B == INFINITY);
-            release = !(__int_as_float(pbits) > theta) && !parked;
-        } else {
-            release = !(__int_as_float(pbits) > rb);
+        bool release = false, parked = false;
+        if (valid) {
+            if (MODE == MODE_LOWER) {
+                const float B = P.focused ? (m < 64 ? s_B[m] : start_bound(P, m)) : INFINITY;
+                const float hd = P.focused ? tile_heuristic(P, m, t / P.TY, t % P.TY) : 0.0f;
+                parked = !(__int_as_float(pbits) + hd < B || B == INFINITY);
+                release = !(__int_as_float(pbits) > theta) && !parked;
+            } else {
+                release = !(__int_as_float(pbits) > rb);
+            }
+            queued[gt] = 0;
+            prio[gt] = INFBITS;
         }
-        queued[gt] = 0;
-        prio[gt] = INFBITS;
-        if (release) {
-            // a launch lasts (work per CU) + (its longest visit) when long visits are handed out last;
-            // tiles a front is still crossing (first visit of the step, or many sweeps last time) go first
-            const bool lng = UFM_LPT && (P.touched[gt] == 0 || P.hint[gt] >= UFM_LONG_SWEEPS);
-            if (lng) P.ready[atomicAdd(&P.ctr->nready[k & 1], 1)] = gt;
-            else P.ready[P.NT - 1 - atomicAdd(&P.ctr->nshort[k & 1], 1)] = gt;
+        // a launch lasts (work per CU) + (its longest visit) when long visits are handed out last;
+        // tiles a front is still crossing (first visit of the step, or many sweeps last time) go first
+        const bool lng = release && UFM_LPT && (P.touched[gt] == 0 || P.hint[gt] >= UFM_LONG_SWEEPS);
+        const int sl = wave_slot(lng, &P.ctr->nready[k & 1]);
+        if (lng) P.ready[sl] = gt;
+        const bool sht = release && !lng;
+        const int ss = wave_slot(sht, &P.ctr->nshort[k & 1]);
+        if (sht) P.ready[P.NT - 1 - ss] = gt;
+        // beyond the bound: park (park_tile, aggregated)
+        const bool prk = valid && !release && (parked || MODE == MODE_RAISE);
+        bool fresh = false;
+        if (prk) {
+            atomicMin(&P.pprio[Q * P.NT + gt], pbits);
+            fresh = atomicExch(&P.pflag[Q * P.NT + gt], 1) == 0;
         }
-        else if (parked || MODE == MODE_RAISE) park_tile(P, Q, gt, pbits);
-        else activate(P, Q, rn, pn, gt, pbits);
+        const int sp = wave_slot(fresh, &P.ctr->npark[Q]);
+        if (fresh) P.park[(size_t)(Q * 2) * P.NT + sp] = gt;
+        // inside the bound, beyond the band: carry over to the next launch (activate, aggregated)
+        const bool carry = valid && !release && !prk;
+        int wmin = carry ? pbits : INFBITS;
+        for (int off = 32; off; off >>= 1) wmin = min(wmin, __shfl_xor(wmin, off));
+        if (wmin != INFBITS && (threadIdx.x & 63) == 0) atomicMin(&P.ctr->lmin[Q][rn], wmin);
+        bool first = false;
+        if (carry) {
+            atomicMin(&P.prio[(size_t)(Q * 2 + pn) * P.NT + gt], pbits);
+            first = atomicExch(&P.queued[(size_t)(Q * 2 + pn) * P.NT + gt], 1) == 0;
+        }
+        const int sc = wave_slot(first, &P.ctr->cnt[Q][rn]);
+        if (first) P.cand[(size_t)(Q * 3 + rn) * P.NT + sc] = gt;
     }
 }
 
