@@ -465,7 +465,9 @@ __global__ __launch_bounds__(NTHR, UFM_RELAX_WAVES) void k_relax(DevParams P, in
         if (!DYN) {
             bool release, parked = false;
             if (MODE == MODE_LOWER) {
-                const float B = P.focused ? start_bound(P, m) : INFINITY;
+                // (the start key as of the beginning of the launch, s_B: re-reading the start elements for
+                //  every tile put two more dependent memory round trips before each visit)
+                const float B = P.focused ? (m < 64 ? s_B[m] : start_bound(P, m)) : INFINITY;
                 const float hd = P.focused ? tile_heuristic(P, m, t / P.TY, t % P.TY) : 0.0f;
                 parked = !(__int_as_float(pbits) + hd < B || B == INFINITY);
                 release = !(__int_as_float(pbits) > theta) && !parked;
