@@ -107,6 +107,15 @@ int ufm_read_map(ufm_t *p, uint8_t *host_map);
  * 0 converges the whole field every step (every element then holds its final value). ---- */
 int ufm_set_param(ufm_t *p, const char *name, double value);
 
+/* ---- back-pointers: the `Info` member of a level-1/2 map element (ExpandedMap.h:27-29; set in
+ * FieldDPlanner_impl.h:86-111, ShiftedGridPlanner_impl.h:131-166, DynamicFastMarching_impl.h:73-99).
+ * Not stored by the engine: derived on demand from the field as min_rhs<level>() derives them
+ * (FD impl:196-208, SG :266-303, DFM :212-268).  info: int32 [nx][ny][2].  Node planners: [0] =
+ * linear index (x * field_ny + y) of the node b with RHS(s) = cost over the edge (b, ccw_neighbor(s, b)),
+ * [1] = -1.  DFM: the two cells of the winning stencil (-1: none, -2: outside the grid).
+ * UFM_ERR_INVALID for a level-0 planner (its map has no Info). ---- */
+int ufm_read_info(ufm_t *p, int x0, int y0, int nx, int ny, int32_t *info);
+
 /* ---- path extraction: replaces LinearInterpolationPathExtractor::extract_path
  * (PathExtraction/LinearInterpolationPathExtractor_impl.h:11-58) and the traversal case tables it
  * calls (ProjectToolkit/InterpolatedTraversal.cpp).  Walks the RHS field from the start position

@@ -58,6 +58,9 @@ def lib():
         L.orc_extract_path_field.argtypes = [vp, i, i, i, vp, i, i, i, f, f, f, f, i, i, i, vp, i, vp, i, pi, pf, pf]
         L.orc_threshold_uchar.restype = i
         L.orc_threshold_uchar.argtypes = [vp]
+        L.orc_min_rhs_info.restype = f
+        L.orc_min_rhs_info.argtypes = [vp, i, i, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
+        L.orc_load_g.argtypes = [vp, vp]
         _LIB = L
     return _LIB
 
@@ -152,6 +155,22 @@ class OraclePlanner:
                                     pts.ctypes.data, cap, costs.ctypes.data, costs.size,
                                     C.byref(nc), C.byref(tc), C.byref(td))
         return pts[:n].copy(), costs[:nc.value].copy(), tc.value, td.value
+
+    def load_g(self, g):
+        g = np.ascontiguousarray(g, np.float32)
+        assert g.shape == self.dims()
+        self.L.orc_load_g(self.h, g.ctypes.data)
+
+    def info_field(self):
+        """min_rhs<level> back-pointers of every element from the current G field: int32 [nx][ny][2]"""
+        nx, ny = self.dims()
+        out = np.empty((nx, ny, 2), np.int32)
+        a, b = C.c_int32(), C.c_int32()
+        for x in range(nx):
+            for y in range(ny):
+                self.L.orc_min_rhs_info(self.h, x, y, C.byref(a), C.byref(b))
+                out[x, y, 0], out[x, y, 1] = a.value, b.value
+        return out
 
     def threshold_uchar(self):
         return self.L.orc_threshold_uchar(self.h)

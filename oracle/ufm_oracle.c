@@ -810,3 +810,21 @@ int orc_extract_path(const orc_t *p, int lookahead, int max_steps, int allow_ind
                                   p->start_px, p->start_py, p->goal_px, p->goal_py, lookahead, max_steps,
                                   allow_indirect, path_xy, cap_pts, costs, cap_costs, n_costs, total_cost, total_dist);
 }
+
+/* ---- back-pointer (INFO) of an element as the level-1/2 min_rhs computes it from the current G
+ * field (FieldDPlanner_impl.h:196-208, ShiftedGridPlanner_impl.h:266-303,
+ * DynamicFastMarching_impl.h:212-268): a pure function of the field, used to check the engine's
+ * ufm_read_info.  Node planners: *b0 = linear index of the node bptr (RHS = cost over the edge
+ * bptr -> ccw_neighbor(bptr)), *b1 = -1; DFM: the two cells of the winning stencil (-1: none, -2:
+ * outside the grid).  Returns the RHS. */
+float orc_min_rhs_info(const orc_t *p, int x, int y, int32_t *b0, int32_t *b1) {
+    int a = -1, b = -1;
+    float rhs;
+    if (p->algo == ORC_ALGO_DFM) rhs = dfm_min_rhs(p, x, y, &a, &b);
+    else if (p->algo == ORC_ALGO_SG && p->lvl == 2) rhs = min_rhs2_node(p, x, y, &a);
+    else rhs = min_rhs1_node(p, x, y, &a);
+    *b0 = a; *b1 = b;
+    return rhs;
+}
+/* test hook: overwrite the G field (e.g. with one read back from the engine) */
+void orc_load_g(orc_t *p, const float *g) { memcpy(p->g, g, p->n * sizeof(float)); }

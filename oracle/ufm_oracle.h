@@ -81,6 +81,10 @@ int orc_extract_path(const orc_t *p, int lookahead, int max_steps, int allow_ind
                      float *path_xy, int cap_pts, float *costs, int cap_costs,
                      int *n_costs, float *total_cost, float *total_dist);
 int orc_threshold_uchar(const orc_t *p);
+/* back-pointer(s) min_rhs<1/2> derives from the current G field (a pure function of it), and a
+ * test hook that loads a G field */
+float orc_min_rhs_info(const orc_t *p, int x, int y, int32_t *b0, int32_t *b1);
+void orc_load_g(orc_t *p, const float *g);
 
 #ifdef __cplusplus
 }

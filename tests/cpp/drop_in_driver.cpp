@@ -57,7 +57,11 @@ int run(int size, const std::vector<uint8_t> &raster, int n_patches, const std::
   double sum = 0;
   long long cnt = 0;
   for (const auto &b : planner.map.buckets)
-    for (const auto &e : b) { sum += std::get<0>(e.second); ++cnt; (void)e.first.x; }
+    for (const auto &e : b) {
+      sum += std::get<0>(e.second); ++cnt; (void)e.first.x;
+      auto info = std::get<2>(e.second);      // the level-1/2 planners' back-pointer member (ExpandedMap.h:27-29)
+      (void)info;
+    }
   std::printf("dump size %lld iterated %lld sum_g %.6f\n", n, cnt, sum);
   return 0;
 }

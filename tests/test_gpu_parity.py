@@ -515,3 +515,38 @@ def test_config4_batch_of_8_maps_2048_dfm():
     paths = b.extract_paths(max_steps=20)
     assert len(paths) == n and all(len(pt[0]) >= 2 and pt[2] > 0 for pt in paths)
     b.close(); p.close()
+
+
+@pytest.mark.parametrize("algo,lvl", [("FD", 1), ("SG", 1), ("SG", 2), ("DFM", 1)])
+def test_back_pointer_view(algo, lvl):
+    """ufm_read_info: the reference's INFO (back-pointers of the level-1/2 planners) derived from the
+    field.  Checked against the oracle's min_rhs<level> evaluated on the very same field (loaded into
+    the oracle), element by element, after a plan and some replans; a level-0 planner has no Info."""
+    width, length = 120, 88
+    cost = ufm_amd.synth.cost_map(17, width, length)
+    start, goal = ufm_amd.synth.start_goal(width, length)
+    o, g = make_pair(ALGOS[algo], lvl, cost, start, goal)
+    assert g.step() == 0
+    for k, s, top, left, patch in ufm_amd.synth.replan_script(17, width, length, n_patches=3, size=15):
+        g.patch_map(patch, top, left); o.patch_map(patch, top, left)
+        g.set_start(*s)
+        assert g.step() == 0
+    field = g.g()
+    o.load_g(field)                       # same raster (patched above), same field
+    ref = o.info_field()
+    got = g.read_info()
+    assert got.shape == ref.shape
+    bad = np.argwhere((got != ref).any(axis=2))
+    assert len(bad) == 0, "%d of %d elements differ, first %r: engine %r oracle %r" % (
+        len(bad), got.shape[0] * got.shape[1], tuple(bad[0]), got[tuple(bad[0])].tolist(), ref[tuple(bad[0])].tolist())
+    # the view says something: most reached elements have a back-pointer
+    assert (got[..., 0] >= 0).sum() > 0.8 * np.isfinite(field).sum()
+    # a window equals the same part of the whole
+    win = g.read_info(10, 20, 30, 40)
+    assert np.array_equal(win, got[10:40, 20:60])
+    z = ufm_amd.Planner(ALGOS[algo], 0)
+    z.set_occupancy_threshold(1); z.set_map(cost); z.set_start(*start); z.set_goal(*goal)
+    assert z.step() == 0
+    with pytest.raises(ufm_amd.UfmError):
+        z.read_info()
+    z.close(); g.close()

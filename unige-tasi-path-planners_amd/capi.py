@@ -20,7 +20,7 @@ SYMBOLS = [
     "ufm_version", "ufm_tile_edge", "ufm_batch_create", "ufm_batch_destroy", "ufm_batch_size",
     "ufm_batch_set_occupancy_threshold", "ufm_batch_set_map", "ufm_batch_patch_map",
     "ufm_batch_set_start", "ufm_batch_set_goal", "ufm_batch_reset", "ufm_batch_step",
-    "ufm_batch_read_field", "ufm_extract_path", "ufm_batch_extract_path",
+    "ufm_batch_read_field", "ufm_extract_path", "ufm_batch_extract_path", "ufm_read_info",
 ]
 
 
@@ -108,6 +108,7 @@ def load_library():
     L.ufm_batch_reset.argtypes = [vp, i]
     L.ufm_batch_step.argtypes = [vp, C.POINTER(Stats)]
     L.ufm_batch_read_field.argtypes = [vp, i, i, i, i, i, vp, vp]
+    L.ufm_read_info.argtypes = [vp, i, i, i, i, vp]
     L.ufm_extract_path.argtypes = [vp, i, i, i, vp, i, vp, i, C.POINTER(PathInfo)]
     L.ufm_batch_extract_path.argtypes = [vp, i, i, i, vp, i, vp, i, C.POINTER(PathInfo)]
     _LIB = L
@@ -216,6 +217,15 @@ class Planner:
 
     def g(self):
         return self.read_field()[0]
+
+    def read_info(self, x0=0, y0=0, nx=None, ny=None):
+        """back-pointers (the reference's INFO of level-1/2 planners) derived from the field: int32 [nx][ny][2]"""
+        ex, ey = self.dims()
+        nx = ex - x0 if nx is None else nx
+        ny = ey - y0 if ny is None else ny
+        out = np.empty((nx, ny, 2), np.int32)
+        _chk(self.L.ufm_read_info(self.h, x0, y0, nx, ny, out.ctypes.data), "ufm_read_info")
+        return out
 
     def extract_path(self, max_steps=20, lookahead=True, allow_indirect=True):
         """LinearInterpolationPathExtractor::extract_path on the device:

@@ -2008,6 +2008,28 @@ int engine_extract_path(Engine *e, int max_steps, int lookahead, int allow_indir
     return UFM_OK;
 }
 
+// Back-pointers of a window of elements, derived from the field (k_info, ufm_path.h).
+int engine_read_info(Engine *e, int m, int x0, int y0, int nx, int ny, int32_t *info) {
+    if (!e || m < 0 || m >= e->nmaps || !e->allocated || !info) return UFM_ERR_INVALID;
+    if (e->opt_lvl == 0) return UFM_ERR_INVALID;            // level 0: the map has no Info member (void)
+    if (x0 < 0 || y0 < 0 || nx <= 0 || ny <= 0 || x0 + nx > e->P.EX || y0 + ny > e->P.EY) return UFM_ERR_INVALID;
+    HIPCHK(hipSetDevice(e->device));
+    const size_t n = (size_t)nx * ny;
+    int32_t *d_out = nullptr;
+    HIPCHK(hipMalloc(&d_out, n * 2 * sizeof(int32_t)));
+    PathField F{};
+    F.G = e->P.G + (size_t)m * e->P.gstride; F.cost = e->P.cost + (size_t)m * e->P.cstride;
+    F.EX = e->P.EX; F.EY = e->P.EY; F.L = e->P.L; F.W = e->P.W; F.pitch = e->P.pitch; F.thr = e->P.thr;
+    F.cells = (e->algo == UFM_ALGO_DFM); F.indirect = (e->algo == UFM_ALGO_FD);   // FD: all five cost cases; SG: B / II / A
+    k_info<<<(unsigned)((n + 255) / 256), 256, 0, e->stream>>>(F, e->opt_lvl, x0, y0, nx, ny, d_out);
+    hipError_t err = hipGetLastError();
+    if (err == hipSuccess) err = hipMemcpyAsync(info, d_out, n * 2 * sizeof(int32_t), hipMemcpyDeviceToHost, e->stream);
+    if (err == hipSuccess) err = hipStreamSynchronize(e->stream);
+    hipFree(d_out);
+    HIPCHK(err);
+    return UFM_OK;
+}
+
 }  // namespace
 
 // ---- C ABI ---------------------------------------------------------------------------
@@ -2161,6 +2183,7 @@ int ufm_batch_step(ufm_batch_t *b, ufm_stats *stats) {
 }
 int ufm_batch_read_field(ufm_batch_t *b, int i, int x0, int y0, int nx, int ny, float *g, float *rhs) { return b ? engine_read_field(b->e, i, x0, y0, nx, ny, g, rhs) : UFM_ERR_INVALID; }
 
+int ufm_read_info(ufm_t *p, int x0, int y0, int nx, int ny, int32_t *info) { return p ? engine_read_info(p->e, 0, x0, y0, nx, ny, info) : UFM_ERR_INVALID; }
 int ufm_extract_path(ufm_t *p, int max_steps, int lookahead, int allow_indirect,
                      float *path_xy, int cap_points, float *step_costs, int cap_costs, ufm_path_info *info) {
     return p ? engine_extract_path(p->e, max_steps, lookahead, allow_indirect, path_xy, cap_points, step_costs, cap_costs, info) : UFM_ERR_INVALID;

@@ -365,3 +365,115 @@ __global__ __launch_bounds__(64) void k_extract_path(PathField F0, size_t gstrid
         o[4] = __int_as_float(step);
     }
 }
+
+// ---- back-pointers (the reference's INFO member of a level-1/2 map element) as a view ----------
+// The reference stores, per expanded element, which neighbours its RHS came from
+// (FieldDPlanner_impl.h:86-111,196-208; ShiftedGridPlanner_impl.h:131-166,266-303;
+// DynamicFastMarching_impl.h:73-99,212-268) -- a device of its serial algorithm (which elements to
+// recompute when a neighbour is raised).  The engine does not need them (an element is invalidated
+// when its neighbours no longer reproduce its value), so they are not stored; this kernel derives
+// them on demand from the converged field, exactly as min_rhs<level>() would.
+// Node planners: out[0] = linear index (x * EY + y) of the node b with RHS(s) = cost over the edge
+// (b, ccw_neighbor(s, b)), out[1] = -1.  DFM: the two cells of the winning stencil (-1: none,
+// -2: outside the grid).
+__device__ __forceinline__ int ring_of(int dx, int dy) {          // Graph.cpp:232-260 rotation order
+    const int idx[3][3] = {{7, 0, 1}, {6, -1, 2}, {5, 4, 3}};
+    return idx[dx + 1][dy + 1];
+}
+__device__ __forceinline__ void ring_at(int r, int &dx, int &dy) {
+    const int RX[8] = {-1, -1, 0, 1, 1, 1, 0, -1}, RY[8] = {0, 1, 1, 1, 0, -1, -1, -1};
+    dx = RX[r & 7]; dy = RY[r & 7];
+}
+__device__ __forceinline__ bool elem_ok(const PathField &F, int x, int y) { return x >= 0 && y >= 0 && x < F.EX && y < F.EY; }
+
+// compute_optimal_cost(s, a, b) with the given neighbour values: the corner traversal cost
+__device__ float node_cost(const PathField &F, int sx, int sy, int ax, int ay, int bx, int by, float ga, float gb) {
+    TSet t;
+    const bool al = (sx == ax) || (sy == ay);
+    t.p0x = (float)sx; t.p0y = (float)sy;
+    t.p1x = al ? ax : bx; t.p1y = al ? ay : by;
+    t.p2x = al ? bx : ax; t.p2y = al ? by : ay;
+    t.g1 = al ? ga : gb; t.g2 = al ? gb : ga;
+    if (t.g1 == INFINITY && t.g2 == INFINITY) return INFINITY;
+    set_costs(F, t);
+    Move m;
+    move_corner(F, t, m);
+    return m.ctg;
+}
+
+// DynamicFastMarching_impl.h:322-351
+__device__ __forceinline__ void dfm_best(const PathField &F, int ax, int ay, int bx, int by, int &ox, int &oy, float &og) {
+    const float ca = field_at(F, ax, ay), cb = field_at(F, bx, by);
+    if (ca < cb) { ox = ax; oy = ay; og = ca; } else { ox = bx; oy = by; og = cb; }
+}
+__device__ float dfm_stencil(int ca, int cb, float ga, float gb, float tau, float h, int &b0, int &b1) {
+    if (ga > gb) { const float tg = ga; ga = gb; gb = tg; const int tc = ca; ca = cb; cb = tc; }
+    if (ga == INFINITY && gb == INFINITY) { b0 = -1; b1 = -1; return INFINITY; }
+    if (tau * h > gb - ga) {
+        b0 = ca; b1 = cb;
+        const float th = tau * h, d = gb - ga;
+        return (ga + gb + sqrt_rn(2 * (th * th) - d * d)) * 0.5f;
+    }
+    b0 = ca; b1 = -1;
+    return ga + tau * h;
+}
+
+__global__ void k_info(PathField F, int lvl, int x0, int y0, int nx, int ny, int32_t *out) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= nx * ny) return;
+    const int x = x0 + e / ny, y = y0 + e % ny;
+    int b0 = -1, b1 = -1;
+    auto lin = [&](int qx, int qy) { return elem_ok(F, qx, qy) ? qx * F.EY + qy : -2; };
+    if (F.cells) {                                        // min_rhs<1>, DynamicFastMarching_impl.h:212-268
+        const float tau = raster_cost(F, x, y);
+        if (tau != INFINITY) {
+            int ax, ay, bx, by, o0, o1, d0, d1; float ga, gb;
+            dfm_best(F, x - 1, y, x + 1, y, ax, ay, ga);
+            dfm_best(F, x, y - 1, x, y + 1, bx, by, gb);
+            const float so = dfm_stencil(lin(ax, ay), lin(bx, by), ga, gb, tau, 1.0f, o0, o1);
+            dfm_best(F, x - 1, y - 1, x + 1, y + 1, ax, ay, ga);
+            dfm_best(F, x + 1, y - 1, x - 1, y + 1, bx, by, gb);
+            const float sd = dfm_stencil(lin(ax, ay), lin(bx, by), ga, gb, tau, PATH_SQRT2, d0, d1);
+            if (sd < so) { b0 = d0; b1 = d1; } else { b0 = o0; b1 = o1; }
+        }
+    } else if (lvl == 2) {                                // ShiftedGridPlanner_impl.h:280-303
+        const int DX[4] = {-1, 1, -1, 1}, DY[4] = {-1, -1, 1, 1};        // Graph::neighbors_diag_4
+        float rhs = INFINITY;
+        for (int i = 0; i < 4; ++i) {
+            const int qx = x + DX[i], qy = y + DY[i];
+            if (!elem_ok(F, qx, qy)) continue;
+            const int r = ring_of(qx - x, qy - y);
+            int dx, dy;
+            ring_at(r + 1, dx, dy); const int ccx = x + dx, ccy = y + dy;
+            ring_at(r + 7, dx, dy); const int cwx = x + dx, cwy = y + dy;
+            const bool v1 = elem_ok(F, ccx, ccy), v2 = elem_ok(F, cwx, cwy);
+            const float g_cc = v1 ? field_at(F, ccx, ccy) : INFINITY, g_cw = v2 ? field_at(F, cwx, cwy) : INFINITY;
+            const float g_q = field_at(F, qx, qy);
+            if (v1 && (!v2 || g_cc <= g_cw)) {
+                const float c = node_cost(F, x, y, qx, qy, ccx, ccy, g_q, g_cc);
+                if (c < rhs) rhs = c;
+                if (rhs == c) b0 = qx * F.EY + qy;
+            } else if (v2 && (!v1 || g_cc > g_cw)) {
+                const float c = node_cost(F, x, y, qx, qy, cwx, cwy, g_q, g_cw);
+                if (c < rhs) rhs = c;
+                if (rhs == c) b0 = cwx * F.EY + cwy;
+            }
+        }
+    } else {                                              // FieldDPlanner_impl.h:196-208, ShiftedGridPlanner_impl.h:266-278
+        const int DX[8] = {-1, -1, 0, 1, 1, 1, 0, -1}, DY[8] = {0, -1, -1, -1, 0, 1, 1, 1};   // Graph::neighbors_8
+        float rhs = INFINITY;
+        for (int i = 0; i < 8; ++i) {
+            const int qx = x + DX[i], qy = y + DY[i];
+            if (!elem_ok(F, qx, qy)) continue;
+            int dx, dy;
+            ring_at(ring_of(qx - x, qy - y) + 1, dx, dy);
+            const int ccx = x + dx, ccy = y + dy;
+            if (!elem_ok(F, ccx, ccy)) continue;
+            const float c = node_cost(F, x, y, qx, qy, ccx, ccy, field_at(F, qx, qy), field_at(F, ccx, ccy));
+            if (c < rhs) rhs = c;
+            if (rhs == c) b0 = qx * F.EY + qy;
+        }
+    }
+    out[2 * e] = b0;
+    out[2 * e + 1] = b1;
+}

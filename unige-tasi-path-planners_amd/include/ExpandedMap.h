@@ -28,11 +28,15 @@ class ExpandedMap {
  public:
   using ElemType = ElemType_;
   using InfoType = InfoType_;
-  using value_ = std::tuple<float, float>;
+  // (g, rhs) for the level-0 planners, (g, rhs, info) for the others -- as the reference's
+  // ExpandedMap.h:27-29, so that std::get<2>(element.second) of a driver compiles
+  using value_ = typename std::conditional<std::is_void<InfoType_>::value, std::tuple<float, float>,
+                                           std::tuple<float, float, typename std::conditional<std::is_void<InfoType_>::value, int, InfoType_>::type>>::type;
   using bucket_ = std::vector<std::pair<const ElemType_, value_>>;
 
-  /** Filled by size(): every element that holds a finite value, as (elem, (g, rhs)) pairs in one
-   * bucket per 256x256 block -- what the reference's `for (auto b : map.buckets)` dump iterates. */
+  /** Filled by size(): every element that holds a finite value, as (elem, (g, rhs[, info])) pairs in
+   * one bucket per 256x256 block -- what the reference's `for (auto b : map.buckets)` dump iterates.
+   * info (level-1/2 planners): the back-pointer(s) ufm_read_info derives from the field. */
   std::vector<bucket_> buckets;
 
   ExpandedMap() = default;
@@ -62,12 +66,20 @@ class ExpandedMap {
     if (ufm_read_field(handle_, 0, 0, nx_, ny_, g.data(), nullptr) != UFM_OK) return 0;
     const int bx = (nx_ >> 8) + 1, by = (ny_ >> 8) + 1;
     self->buckets.resize(static_cast<size_t>(bx) * by);
+    std::vector<int32_t> info;
+    if constexpr (!std::is_void<InfoType_>::value) {
+      info.resize(static_cast<size_t>(nx_) * ny_ * 2);
+      if (ufm_read_info(handle_, 0, 0, nx_, ny_, info.data()) != UFM_OK) return 0;
+    }
     size_t n = 0;
     for (int x = 0; x < nx_; ++x)
       for (int y = 0; y < ny_; ++y) {
-        const float v = g[static_cast<size_t>(x) * ny_ + y];
+        const size_t e = static_cast<size_t>(x) * ny_ + y;
+        const float v = g[e];
         if (v < INFINITY) {
-          self->buckets[static_cast<size_t>(x >> 8) * by + (y >> 8)].emplace_back(ElemType(x, y), value_(v, v));
+          auto &bucket = self->buckets[static_cast<size_t>(x >> 8) * by + (y >> 8)];
+          if constexpr (std::is_void<InfoType_>::value) bucket.emplace_back(ElemType(x, y), value_(v, v));
+          else bucket.emplace_back(ElemType(x, y), value_(v, v, make_info(info[2 * e], info[2 * e + 1])));
           ++n;
         }
       }
@@ -82,6 +94,14 @@ class ExpandedMap {
   void clear() noexcept { invalidate(); buckets.clear(); }
 
  private:
+  // linear element index -> Node / Cell (negative: "none", default-constructed like the reference's Node{} / Cell{})
+  ElemType elem_of(int32_t idx) const { return idx >= 0 ? ElemType(idx / ny_, idx % ny_) : ElemType(); }
+  template <typename U = InfoType_>
+  typename std::conditional<std::is_void<U>::value, int, U>::type make_info(int32_t a, int32_t b) const {
+    if constexpr (std::is_same<U, ElemType>::value) { (void)b; return elem_of(a); }
+    else if constexpr (std::is_same<U, std::pair<ElemType, ElemType>>::value) return {elem_of(a), elem_of(b)};
+    else { (void)a; (void)b; return 0; }
+  }
   static constexpr int kBlock = 64;
   float value(int x, int y) const {
     if (!handle_ || x < 0 || y < 0 || x >= nx_ || y >= ny_) return INFINITY;
