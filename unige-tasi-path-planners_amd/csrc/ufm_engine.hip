@@ -51,6 +51,9 @@ constexpr int NTHR = 1024;     // 16 waves; four lanes per node, each wave owns 
 #ifndef UFM_CAUSAL_FILTER
 #define UFM_CAUSAL_FILTER 1    // do not wake a neighbour tile that a changed border value cannot influence
 #endif
+#ifndef UFM_STATIC_FIRST
+#define UFM_STATIC_FIRST 1     // cursor hand-out: first tile of a workgroup by index, the rest through the cursor
+#endif
 #ifndef UFM_LPT
 #define UFM_LPT 1              // longest-expected-first hand-out of the ready list
 #endif
@@ -443,13 +446,20 @@ __global__ __launch_bounds__(NTHR, UFM_RELAX_WAVES) void k_relax(DevParams P, in
     }
     const int colour = ((nd >> 2) & 1) | ((nd & 1) << 1);
 
+    // A workgroup's first tile is the one at its own index -- no round trip to the shared cursor
+    // before the first visit (256 same-address atomics across 8 XCDs take microseconds); the launch
+    // has one workgroup per CU, so all of them start at once and the longest-first order is kept.
+    bool first_pop = UFM_STATIC_FIRST;
+    unsigned long long st_visits = 0, st_iters = 0, st_evals = 0;   // thread 4's per-workgroup statistics
+    int st_lmax = 0;
     for (int i = blockIdx.x;; i += gridDim.x) {
-        if (DYN) {                                         // next ready tile, whoever is free takes it
+        if (DYN && !first_pop) {                           // next ready tile, whoever is free takes it
             __syncthreads();
-            if (tid == 0) s_min = atomicAdd(&P.ctr->rcursor[k & 1], 1);
+            if (tid == 0) s_min = (UFM_STATIC_FIRST ? gridDim.x : 0) + atomicAdd(&P.ctr->rcursor[k & 1], 1);
             __syncthreads();
             i = s_min;
         }
+        first_pop = false;
         if (i >= n) {
 #ifdef UFM_TIMING
             if (MODE == MODE_LOWER && tid == 0) trace_rec(k, 1, tkb, wall_clock64(), 0);
@@ -701,12 +711,13 @@ __global__ __launch_bounds__(NTHR, UFM_RELAX_WAVES) void k_relax(DevParams P, in
             const int dr = tid / 3 - 1, dc = tid % 3 - 1;
             if (tid == 4) {
                 if (!conv || s_bmin[4] != INFBITS) activate(P, Q, rn, pn, gt, min(s_bmin[4], INFBITS - 1));   // sweep cap hit / border rose: come back
-                atomicMax(&P.lmax[k & (LMAX - 1)], s_misc[3]);
                 P.hint[gt] = s_misc[3];
-                atomicAdd(&P.ctr->tile_visits, 1ull);
-                if (MODE == MODE_RAISE) atomicAdd(&P.ctr->raise_visits, 1ull);
-                atomicAdd(&P.ctr->tile_iters, (unsigned long long)s_misc[3]);
-                atomicAdd(&P.ctr->elem_evals, 16ull * (unsigned long long)s_misc[2]);
+                // statistics: summed in this thread's registers, flushed once when the workgroup is done
+                // (same-address atomics from 256 CUs are memory-side operations; five per visit add up)
+                st_lmax = max(st_lmax, s_misc[3]);
+                st_visits += 1;
+                st_iters += (unsigned long long)s_misc[3];
+                st_evals += 16ull * (unsigned long long)s_misc[2];
             } else if (s_bmin[tid] != INFBITS) {
                 const int ntx = tx + dr, nty = ty + dc;
                 if (ntx >= 0 && ntx < P.TX && nty >= 0 && nty < P.TY) activate(P, Q, rn, pn, m * P.NTm + ntx * P.TY + nty, s_bmin[tid]);
@@ -726,6 +737,13 @@ __global__ __launch_bounds__(NTHR, UFM_RELAX_WAVES) void k_relax(DevParams P, in
             }
         }
 #endif
+    }
+    if (tid == 4 && st_visits) {
+        atomicMax(&P.lmax[k & (LMAX - 1)], st_lmax);
+        atomicAdd(&P.ctr->tile_visits, st_visits);
+        if (MODE == MODE_RAISE) atomicAdd(&P.ctr->raise_visits, st_visits);
+        atomicAdd(&P.ctr->tile_iters, st_iters);
+        atomicAdd(&P.ctr->elem_evals, st_evals);
     }
 }
 
@@ -1203,6 +1221,7 @@ struct Engine {
     float *h_bnd = nullptr;          // pinned [nmaps]
     int last_active = 1;             // queue length at the last host check: long queues go through k_triage
     int grid_relax = 512;
+    int dyn_grid = 256;              // workgroups of a cursor hand-out launch: the number of CUs
     int small_grid = 1 << 30;        // workgroups of a relax launch over a short queue (measured: no gain, off)
     int max_iters = 32;              // sweep cap per tile visit (x4 patch sweeps per wave): a tile that needs more is
                                      // re-queued instead of holding the whole launch (measured optimum on 4096^2)
@@ -1423,6 +1442,7 @@ int Engine::launch_relax(int mode, float rbound, hipEvent_t e0, hipEvent_t e1) {
     // a short queue (replans: a handful of tiles per launch) does not need the whole chip: a small
     // grid starts, and when there is nothing left to do ends, sooner
     if (!dyn && last_active <= small_grid / 2 && small_grid < grid_relax) g = dim3(small_grid);
+    if (dyn && UFM_STATIC_FIRST) g = dim3(std::min(grid_relax, dyn_grid));   // one resident workgroup per CU
     if (dyn) {
         if (mode == MODE_LOWER) k_triage<MODE_LOWER><<<64, 256, 0, stream>>>(P, iter[q], delta, rbound);
         else k_triage<MODE_RAISE><<<64, 256, 0, stream>>>(P, iter[q], delta, rbound);
@@ -1838,6 +1858,7 @@ int engine_create(Engine **out, int n_maps, int algo, int opt_lvl, int use_heuri
     hipDeviceProp_t prop;
     HIPCHK(hipGetDeviceProperties(&prop, device_id));
     e->grid_relax = prop.multiProcessorCount * 2;
+    e->dyn_grid = prop.multiProcessorCount;
     HIPCHK(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
     {   // counters + sequence flag in one host-coherent, device-mapped allocation
         const size_t flag_off = (sizeof(DevCounters) + 63) / 64 * 64;
@@ -2126,6 +2147,7 @@ int ufm_set_param(ufm_t *p, const char *name, double value) {
     else if (!std::strcmp(name, "batch")) e->batch_fixed = (int)value;
     else if (!std::strcmp(name, "grid")) e->grid_relax = value < 1 ? 1 : (int)value;
     else if (!std::strcmp(name, "small_grid")) e->small_grid = value < 1 ? 1 : (int)value;
+    else if (!std::strcmp(name, "dyn_grid")) e->dyn_grid = value < 1 ? 1 : (int)value;
     else if (!std::strcmp(name, "spin_wait")) e->spin_wait = value != 0;
     else if (!std::strcmp(name, "fuse_control")) e->fuse_control = value != 0;
     else if (!std::strcmp(name, "graph")) e->use_graph = value != 0;
