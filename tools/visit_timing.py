@@ -61,7 +61,13 @@ def trace_report():
                   np.median(first_start), np.percentile(first_start, 90), first_start.max(),
                   list((r[v, 3] & 255)[np.argsort(dur)[-5:]].astype(int))))
         w = r[v, 3]
-        sw, seen, hint, n0, n1 = (w & 255).astype(int), ((w >> 8) & 255).astype(int), ((w >> 16) & 255).astype(int), ((w >> 24) & 0xFFFF).astype(int), ((w >> 40) & 0xFFFF).astype(int)
+        sw, seen, hint, n0, n1 = (w & 255).astype(int), ((w >> 8) & 255).astype(int), ((w >> 16) & 255).astype(int), ((w >> 24) & 0xFFFF).astype(int), ((w >> 40) & 0xFFF).astype(int)
+        rank = ((w >> 52) & 0xFF).astype(int)
+        first = seen == 0
+        for lo_, hi_ in ((0, 64), (64, 128), (128, 192), (192, 256)):
+            sel = first & (rank >= lo_) & (rank < hi_)
+            if sel.any():
+                print("      first visits with band position %3d..%3d: %4d, mean %.1f us, over 14 us: %d" % (lo_, hi_, int(sel.sum()), dur[sel].mean(), int((dur[sel] > 14).sum())))
         long_ = dur > 14.0
         def pr(name, pred):
             tp = int((pred & long_).sum()); fp = int((pred & ~long_).sum()); fn = int((~pred & long_).sum())

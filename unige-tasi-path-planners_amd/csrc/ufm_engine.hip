@@ -112,6 +112,7 @@ struct DevParams {
     int *cand;                  // [2 queues][3][NT] queued tiles (global tile ids), ring of three lists
     int *ready;                 // [NT] tiles released by k_triage for the following relax launch
     int *hint;                  // [NT] sweeps the tile's last visit took (longest-first hand-out)
+    int *rank;                  // [NT] diagnostics (UFM_TIMING): position of the tile's priority inside the band, 0..255
     int *park;                  // [2 queues][2][NT] parked tiles (list + scratch for compaction)
     int *pflag;                 // [2 queues][NT] tile is in the park list
     int *pprio;                 // [2 queues][NT] its priority (float bits)
@@ -535,6 +536,7 @@ __global__ __launch_bounds__(NTHR, UFM_RELAX_WAVES) void k_relax(DevParams P, in
         UFM_TICK(tk1);
 #ifdef UFM_TIMING
         const int dbg_hint = P.hint[gt];
+        const int dbg_rank = P.rank[gt];
         const int dbg_ninf0 = __syncthreads_count(io_on && gl0 == INFINITY);
 #endif
         if (s_misc[0] && io_on) P.Gprev[(size_t)m * P.gstride + gidx] = gl0;
@@ -734,7 +736,7 @@ __global__ __launch_bounds__(NTHR, UFM_RELAX_WAVES) void k_relax(DevParams P, in
                 const unsigned long long bin = (tk3 - tk0) / 200;
                 atomicAdd(&g_tdiag[8 + (bin < 31 ? bin : 31)], 1ull);
                 atomicAdd(&g_tdiag[40 + (s_misc[3] < 23 ? s_misc[3] : 23)], 1ull);   // histogram of per-wave sweep counts / 1
-                trace_rec(k, 0, tk0, tk3, (long long)(s_misc[3] & 255) | ((long long)min(s_misc[1], 255) << 8) | ((long long)min(dbg_hint, 255) << 16) | ((long long)dbg_ninf0 << 24) | ((long long)dbg_ninf1 << 40));
+                trace_rec(k, 0, tk0, tk3, (long long)(s_misc[3] & 255) | ((long long)min(s_misc[1], 255) << 8) | ((long long)min(dbg_hint, 255) << 16) | ((long long)dbg_ninf0 << 24) | ((long long)dbg_ninf1 << 40) | ((long long)dbg_rank << 52));
             }
         }
 #endif
@@ -801,6 +803,12 @@ __global__ void k_triage(DevParams P, int k, float delta, float rbound) {
         // a launch lasts (work per CU) + (its longest visit) when long visits are handed out last;
         // tiles a front is still crossing (first visit of the step, or many sweeps last time) go first
         const bool lng = release && UFM_LPT && (P.touched[gt] == 0 || P.hint[gt] >= UFM_LONG_SWEEPS);
+#ifdef UFM_TIMING
+        if (release && MODE == MODE_LOWER) {
+            const float lo = __int_as_float(P.ctr->lmin[Q][r]);
+            P.rank[gt] = (int)fminf(255.0f, fmaxf(0.0f, 255.0f * (__int_as_float(pbits) - lo) / fmaxf(delta, 1e-6f)));
+        }
+#endif
         const int sl = wave_slot(lng, &P.ctr->nready[k & 1]);
         if (lng) P.ready[sl] = gt;
         const bool sht = release && !lng;
@@ -1250,7 +1258,7 @@ struct Engine {
 
 void Engine::release() {
     if (!allocated) return;
-    hipFree(P.G); hipFree(P.Gprev); hipFree(P.cost); hipFree(P.goal); hipFree(P.cand); hipFree(P.ready); hipFree(P.hint); hipFree(P.park); hipFree(P.pflag); hipFree(P.pprio); hipFree(P.queued); hipFree(P.prio); hipFree(P.start); hipFree(P.bnd); hipFree(P.spos);
+    hipFree(P.G); hipFree(P.Gprev); hipFree(P.cost); hipFree(P.goal); hipFree(P.cand); hipFree(P.ready); hipFree(P.hint); hipFree(P.rank); hipFree(P.park); hipFree(P.pflag); hipFree(P.pprio); hipFree(P.queued); hipFree(P.prio); hipFree(P.start); hipFree(P.bnd); hipFree(P.spos);
     hipFree(P.touched); hipFree(P.tlist); hipFree(P.sflag); hipFree(P.slist); hipFree(P.slist2);
     hipFree(P.mark); hipFree(P.num_updated); hipFree(P.consume); hipFree(P.lmax); hipFree(P.ctr);
     hipFree(d_scratch);
@@ -1282,6 +1290,8 @@ int Engine::alloc(int width, int length) {
     HIPCHK(hipMalloc(&P.cand, sizeof(int) * 6 * P.NT));
     HIPCHK(hipMalloc(&P.ready, sizeof(int) * P.NT));
     HIPCHK(hipMalloc(&P.hint, sizeof(int) * P.NT));
+    HIPCHK(hipMalloc(&P.rank, sizeof(int) * P.NT));
+    HIPCHK(hipMemsetAsync(P.rank, 0, sizeof(int) * P.NT, stream));
 
     HIPCHK(hipMemsetAsync(P.hint, 0, sizeof(int) * P.NT, stream));
     HIPCHK(hipMalloc(&P.park, sizeof(int) * 4 * P.NT));
