@@ -7,6 +7,8 @@ TAG=${1:-r1}
 OUT=gpurun_out/profiles_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+mkdir -p build
+[ -x build/traffic_calib ] || /opt/rocm/bin/hipcc -O2 --offload-arch=gfx950 -o build/traffic_calib tools/traffic_calib.hip
 BENCH="python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -- $BENCH > $OUT/bench_kernel_trace.log 2>&1
 cp $(find $OUT/kt -name "*kernel_stats.csv" | head -1) $OUT/${TAG}_kernel_stats.csv
