@@ -3,6 +3,7 @@ import numpy as np
 import pytest
 
 import ufm_amd
+import oracle_py as orc
 from helpers import ALGOS, check_parity, make_pair
 
 pytestmark = pytest.mark.gpu
@@ -550,3 +551,49 @@ def test_back_pointer_view(algo, lvl):
     with pytest.raises(ufm_amd.UfmError):
         z.read_info()
     z.close(); g.close()
+
+
+@pytest.mark.parametrize("algo,lvl", [("FD", 1), ("SG", 2), ("DFM", 1)])
+def test_random_small_maps_with_obstacles_and_patches(algo, lvl):
+    """Seeded random cases at awkward sizes: white-noise costs (no smoothness at all), 15 % obstacle
+    cells, random start / goal, random rectangular patches that add and remove obstacles, thresholds
+    below 1.  Every step is compared with the oracle (and the extracted path on the same field)."""
+    rng = np.random.default_rng(20260 + lvl)
+    n_cases = 14
+    for case in range(n_cases):
+        width, length = int(rng.integers(2, 70)), int(rng.integers(2, 70))
+        cost = rng.integers(1, 255, (length, width), dtype=np.uint8)
+        cost[rng.random((length, width)) < 0.15] = 255
+        thr = float(rng.choice([1.0, 1.0, 0.9, 0.6]))
+        free = np.argwhere(cost < int(thr * 255))
+        if len(free) < 2:
+            continue
+        a, b = free[rng.integers(len(free))], free[rng.integers(len(free))]
+        start, goal = (float(a[0]), float(a[1])), (float(b[0]), float(b[1]))
+        heur = bool(case % 3 == 0) and algo != "DFM"
+        o, g = make_pair(ALGOS[algo], lvl, cost, start, goal, thr=thr, heuristic=heur, hm=1.0)
+        what = "%s case %d (%dx%d thr %.1f heur %d)" % (algo, case, width, length, thr, heur)
+        assert o.step() == 0 and g.step() == 0
+        check_parity(o, g, what, below_start_key=True)
+        cur = cost.copy()
+        for k in range(4):
+            ph, pw = int(rng.integers(1, min(length, 20) + 1)), int(rng.integers(1, min(width, 20) + 1))
+            top, left = int(rng.integers(0, length - ph + 1)), int(rng.integers(0, width - pw + 1))
+            patch = rng.integers(1, 255, (ph, pw), dtype=np.uint8)
+            patch[rng.random((ph, pw)) < 0.15] = 255
+            cur[top:top + ph, left:left + pw] = patch
+            free = np.argwhere(cur < int(thr * 255))
+            a = free[rng.integers(len(free))] if len(free) else np.array([0, 0])
+            s = (float(a[0]), float(a[1]))
+            for p in (o, g):
+                p.patch_map(patch, top, left)
+                p.set_start(*s)
+                assert p.step() == 0
+            assert g.num_nodes_updated == o.num_updated, what
+            check_parity(o, g, what + " patch %d" % k, below_start_key=True)
+            dev = g.extract_path(max_steps=30, allow_indirect=(algo != "SG"))
+            ref = orc.extract_path_field(g.read_field()[1], algo == "DFM", cur, int(thr * 255), s, goal,
+                                         max_steps=30, allow_indirect=(algo != "SG"))
+            assert np.array_equal(dev[0], ref[0]) and np.array_equal(dev[1], ref[1]) and dev[2] == ref[2], what
+        assert np.array_equal(g.read_map(width, length), cur)
+        g.close()
