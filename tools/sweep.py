@@ -35,6 +35,9 @@ for mi in [int(v) for v in a.max_iters.split(",")]:
   for sc in [float(v) for v in a.scales.split(",")]:
     p.set_param("delta_scale", sc)
     p.set_param("max_iters", mi)
+    for kv in a.param:          # after the swept ones: a --param may refine them (e.g. max_iters_short)
+        name, val = kv.split("=")
+        p.set_param(name, float(val))
     for rep in range(a.reps):
         p.set_map(cost); p.reset(); p.set_start(*start); p.set_goal(*goal)
         t0 = time.perf_counter()
