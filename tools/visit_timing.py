@@ -63,6 +63,9 @@ def trace_report():
         w = r[v, 3]
         sw, seen, hint, n0, n1 = (w & 255).astype(int), ((w >> 8) & 255).astype(int), ((w >> 16) & 255).astype(int), ((w >> 24) & 0xFFFF).astype(int), ((w >> 40) & 0xFFF).astype(int)
         rank = ((w >> 52) & 0xFF).astype(int)
+        print("      earlier visits of the same tile in this step (0,1,2,..,>=9): %s | sweeps by earlier visits: %s" % (
+            np.bincount(np.minimum(seen, 9), minlength=10).tolist(),
+            [round(float(sw[np.minimum(seen, 9) == v].mean()), 1) if (np.minimum(seen, 9) == v).any() else 0 for v in range(10)]))
         first = seen == 0
         for lo_, hi_ in ((0, 64), (64, 128), (128, 192), (192, 256)):
             sel = first & (rank >= lo_) & (rank < hi_)

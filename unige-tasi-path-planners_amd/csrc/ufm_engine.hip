@@ -52,6 +52,12 @@ constexpr int NTHR = 1024;     // 16 waves; four lanes per node, each wave owns 
 #ifndef UFM_CAUSAL_FILTER
 #define UFM_CAUSAL_FILTER 1    // do not wake a neighbour tile that a changed border value cannot influence
 #endif
+#ifndef UFM_DFM_LAX_VISITS
+#define UFM_DFM_LAX_VISITS 16     // DFM: after this many visits of a tile in one step a 1-ulp rise is rounding noise
+#endif
+#ifndef UFM_DFM_QUIET_VISITS
+#define UFM_DFM_QUIET_VISITS 24   // DFM: ... and a decrease of <= 4 ulp no longer wakes the neighbours
+#endif
 #ifndef UFM_STATIC_FIRST
 #define UFM_STATIC_FIRST 1     // cursor hand-out: first tile of a workgroup by index, the rest through the cursor
 #endif
@@ -571,7 +577,7 @@ __global__ __launch_bounds__(NTHR, UFM_RELAX_WAVES) void k_relax(DevParams P, in
         // (4-colouring: no two 8-neighbours share one).
         int cnt[PPW] = {};
         int tot = 0;
-        const bool lax = (ALGO == UFM_ALGO_DFM) && (s_misc[1] > 16);
+        const bool lax = (ALGO == UFM_ALGO_DFM) && (s_misc[1] > UFM_DFM_LAX_VISITS);
         bool conv = false;
 #ifdef UFM_TIMING
         const bool wtrace_on = DYN && MODE == MODE_LOWER && k == UFM_TRACE_K0 && i == 0;
@@ -672,7 +678,7 @@ __global__ __launch_bounds__(NTHR, UFM_RELAX_WAVES) void k_relax(DevParams P, in
             bool significant = true;
             if (ALGO == UFM_ALGO_DFM && MODE == MODE_LOWER && gf < INFINITY && gl0 < INFINITY) {
                 const int du = __float_as_int(gf) - __float_as_int(gl0);
-                if (du > 0 ? du <= 4 : (s_misc[1] > 24 && du >= -4)) significant = false;
+                if (du > 0 ? du <= 4 : (s_misc[1] > UFM_DFM_QUIET_VISITS && du >= -4)) significant = false;
             }
             // priority handed to a neighbour: the new value (lowering) / the value that was
             // invalidated (raising: the reference's key of an under-consistent element, min(g,rhs) = g)
