@@ -35,3 +35,13 @@ def test_replan_script_shapes():
         assert patch.shape == (31, 31) and patch.min() >= 1 and patch.max() <= 200
         assert 0 <= top <= 200 - 31 and 0 <= left <= 300 - 31
         assert 0 <= px < 200 and 0 <= py < 300
+
+
+def test_maps_are_c_contiguous():
+    """consumers hand out the raw buffer (bench.py: torch.from_numpy(cost).to(device).data_ptr());
+    a column-major array there is the transposed map"""
+    import ufm_amd
+    c = ufm_amd.synth.cost_map(7, 96, 64)
+    assert c.flags["C_CONTIGUOUS"] and c.shape == (64, 96)
+    for k, s, top, left, patch in ufm_amd.synth.replan_script(7, 96, 64, n_patches=2):
+        assert patch.flags["C_CONTIGUOUS"]
