@@ -1,0 +1,70 @@
+"""Committed oracle outputs (tests/golden/oracle_vectors.npz, made by make_oracle_vectors.py):
+CPU -- the oracle library still reproduces them bit for bit; GPU -- the engine matches them through
+the C ABI without the oracle library in the loop."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+import make_oracle_vectors as gen   # noqa: E402
+import ufm_amd                      # noqa: E402
+
+VEC = np.load(os.path.join(ROOT, "tests", "golden", "oracle_vectors.npz"))
+
+
+def case(algo, lvl, heur):
+    pre = "%s%d%s_" % (algo, lvl, "h" if heur else "")
+    return {k[len(pre):]: VEC[k] for k in VEC.files if k.startswith(pre)}
+
+
+@pytest.mark.parametrize("algo,lvl,heur", gen.CASES)
+def test_oracle_reproduces_committed_vectors(algo, lvl, heur):
+    now, then = gen.run_case(algo, lvl, heur), case(algo, lvl, heur)
+    assert sorted(now) == sorted(then)
+    for k in then:
+        assert np.array_equal(now[k], then[k]), "%s-%d%s: %s changed" % (algo, lvl, "h" if heur else "", k)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("algo,lvl,heur", gen.CASES)
+def test_engine_matches_committed_vectors(algo, lvl, heur):
+    c = case(algo, lvl, heur)
+    cost, start, goal = c["cost"], tuple(c["start"]), tuple(c["goal"])
+    g = ufm_amd.Planner(gen.ALGOS[algo], lvl, bool(heur))
+    g.reset(); g.set_occupancy_threshold(1); g.set_heuristic_multiplier(float(cost.min()))
+    g.set_map(cost); g.set_start(*start); g.set_goal(*goal)
+    n_steps = 1 + len(c["patches"])
+    shape = g.dims()
+    for i in range(n_steps):
+        if i > 0:
+            top, left = c["patch_pos"][i - 1]
+            g.patch_map(c["patches"][i - 1], int(top), int(left))
+            g.set_start(*c["patch_start"][i - 1])
+        assert g.step() == 0
+        mask = np.unpackbits(c["mask%d" % i])[: shape[0] * shape[1]].astype(bool).reshape(shape)
+        got, want = g.g()[mask], c["g%d" % i]
+        what = "%s-%d%s step %d" % (algo, lvl, "h" if heur else "", i)
+        if algo == "DFM":      # tolerance as in helpers.check_parity
+            assert np.all(np.abs(got.astype(np.float64) - want) <= 2e-6 * want + 1e-30), what
+        else:
+            assert np.array_equal(got, want), what
+        if i > 0:
+            assert g.num_nodes_updated == int(c["updated%d" % i][0]), what
+        pts, costs, tc, td = g.extract_path(max_steps=30, allow_indirect=(algo != "SG"))
+        ref = c["path%d" % i]
+        n = min(len(pts), len(ref))
+        same = np.abs(pts[:n] - ref[:n]).max(axis=1) <= 1e-3
+        if algo != "DFM":
+            assert len(pts) == len(ref) and same.all(), what
+            assert abs(tc - c["pathcost%d" % i][0]) <= 1e-4 * abs(c["pathcost%d" % i][0]), what
+        elif not (len(pts) == len(ref) and same.all()):
+            # DFM: node values average four cells; the paths may part where a way point touches a cell beyond the
+            # start's key (not final on either side, see test_gpu_path.close_path_while_final)
+            j = int(np.argmin(same)) if not same.all() else n
+            assert j >= 1, what
+            x, y = int(np.floor(pts[j - 1][0])), int(np.floor(pts[j - 1][1]))
+            assert not mask[max(x - 2, 0):x + 3, max(y - 2, 0):y + 3].all(), what
+    g.close()
