@@ -46,3 +46,19 @@ def test_bad_arguments_rejected():
     assert lib.ufm_create(ctypes.byref(h), 7, 0, 0, 0) == -22          # unknown planner family
     assert lib.ufm_create(ctypes.byref(h), ufm_amd.ALGO_FD, 2, 0, 0) == -22   # only SG has level 2
     assert lib.ufm_version().startswith(b"ufm-gfx950")
+
+
+def test_header_is_plain_c(tmp_path):
+    """include/ufm.h is the drop-in boundary: it must compile as C (no C++ in the signatures) and a C
+    program must link against libufm.so"""
+    import subprocess
+    src = tmp_path / "abi.c"
+    src.write_text('#include "ufm.h"\n#include <stdio.h>\n'
+                   'int main(void) { ufm_stats s; ufm_path_info pi; (void)s; (void)pi;\n'
+                   '  printf("%s tile %d\\n", ufm_version(), ufm_tile_edge()); return 0; }\n')
+    exe = tmp_path / "abi"
+    pkg = os.path.dirname(ufm_amd.library_path())
+    subprocess.check_call(["gcc", "-std=c99", "-pedantic", "-Wall", "-Werror", "-I" + os.path.join(ROOT, "include"),
+                           str(src), "-o", str(exe), "-L" + pkg, "-lufm", "-Wl,-rpath," + pkg])
+    out = subprocess.check_output([str(exe)], text=True)
+    assert out.startswith("ufm-gfx950")
