@@ -1,0 +1,31 @@
+"""GPU box: replans of a batch (every map gets its own patch and start move per step)."""
+import argparse, os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import ufm_amd
+ap = argparse.ArgumentParser()
+ap.add_argument("--size", type=int, default=2048)
+ap.add_argument("--maps", type=int, default=8)
+ap.add_argument("--algo", default="DFM")
+ap.add_argument("--patches", type=int, default=30)
+a = ap.parse_args()
+algo = {"FD": 0, "SG": 1, "DFM": 2}[a.algo]
+n, size = a.maps, a.size
+b = ufm_amd.BatchPlanner(n, algo, 1 if algo != 1 else 2)
+b.set_occupancy_threshold(1)
+start, goal = ufm_amd.synth.start_goal(size, size)
+scripts = []
+for i in range(n):
+    b.set_map(i, ufm_amd.synth.cost_map(1000 + i, size, size)); b.set_start(i, *start); b.set_goal(i, *goal)
+    scripts.append(list(ufm_amd.synth.replan_script(1000 + i, size, size, n_patches=a.patches)))
+t0 = time.perf_counter(); assert b.step() == 0; t1 = time.perf_counter()
+cells = 0
+for k in range(a.patches):
+    for i in range(n):
+        _, s, top, left, patch = scripts[i][k]
+        b.patch_map(i, patch, top, left); b.set_start(i, *s)
+    assert b.step() == 0
+    cells += b.stats.expanded
+t2 = time.perf_counter()
+print("%s %d x %d^2: plan %.1f ms; %d batch replans %.2f ms each (%d launches per step, %.0f cells per step)" % (
+    a.algo, n, size, (t1 - t0) * 1e3, a.patches, (t2 - t1) * 1e3 / a.patches, b.stats.launches, cells / a.patches))

@@ -1253,7 +1253,7 @@ struct Engine {
     int launch_relax(int mode, float rbound, hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr);
     int fetch_counters();
     int wait_published();
-    int win_raise[6] = {3, 3, 3, 3, 3, 3}, win_lower[6] = {4, 4, 4, 4, 4, 4}, win_pos = 0;   // launches recent replans needed
+    int win_raise[6] = {8, 8, 8, 8, 8, 8}, win_lower[6] = {8, 8, 8, 8, 8, 8}, win_pos = 0;   // launches recent replans needed
     int run_phase(int mode, float rbound, uint32_t *launches, float *kernel_ms, uint32_t *timed);
     int profile_stride = 4;          // profiling: every n-th launch of a plan is bracketed by events
     int reset_queues();
