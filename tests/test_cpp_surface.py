@@ -73,3 +73,16 @@ def test_driver_matches_python_binding(tmp_path, algo):
     assert int(m.group(1)) == int(m.group(2)) == int(np.isfinite(g).sum())
     assert abs(float(m.group(3)) - float(g[np.isfinite(g)].astype(np.float64).sum())) <= 1e-6 * float(m.group(3))
     p.close()
+
+
+@pytest.mark.parametrize("driver", ["FDSTAR", "SGDFM", "DFM"])
+@pytest.mark.parametrize("define", [[], ["-DNO_HEURISTIC"]])
+def test_reference_drivers_compile_unmodified_against_the_mirror(driver, define):
+    """The drop-in claim itself: the reference's own driver sources (Tests/Planners/*/main.cpp) are
+    parsed and type-checked against the mirrored headers, unmodified (g++ -fsyntax-only: nothing is
+    built or copied).  Only where the reference tree is mounted (not on the GPU box)."""
+    src = os.path.join("/root/reference/Tests/Planners", driver, "main.cpp")
+    if not os.path.exists(src):
+        pytest.skip("reference tree not present")
+    subprocess.check_call(["g++", "-std=c++17", "-fsyntax-only", "-Wall"] + define +
+                          ["-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(PKG, "include"), src])
