@@ -58,6 +58,9 @@ constexpr int NTHR = 1024;     // 16 waves; four lanes per node, each wave owns 
 #ifndef UFM_DFM_QUIET_VISITS
 #define UFM_DFM_QUIET_VISITS 24   // DFM: ... and a decrease of <= 4 ulp no longer wakes the neighbours
 #endif
+#ifndef UFM_DPP_MIN_ASM
+#define UFM_DPP_MIN_ASM 1
+#endif
 #ifndef UFM_STATIC_FIRST
 #define UFM_STATIC_FIRST 1     // cursor hand-out: first tile of a workgroup by index, the rest through the cursor
 #endif
@@ -346,10 +349,23 @@ template <> struct QuadConsts<UFM_ALGO_FD> {
 };
 
 __device__ __forceinline__ float quad_min(float v) {
+#if UFM_DPP_MIN_ASM
+    // v_min_f32 with a DPP source operand: one instruction per step instead of mov_dpp + canonicalise + min
+    // (IEEE mode: v_min_f32 returns the non-NaN operand like fminf; the values here are never NaN).
+    // The s_nop covers the VALU-write -> DPP-read hazard of the second step.
+    float r;
+    asm volatile("s_nop 1\n\t"      // the compiler does not see a DPP read of %1 in here: cover its hazard too
+                 "v_min_f32_dpp %0, %1, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 1\n\t"
+                 "v_min_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf"
+                 : "=&v"(r) : "v"(v));
+    return r;
+#else
     int x = __float_as_int(v);
     v = fminf(v, __int_as_float(__builtin_amdgcn_update_dpp(x, x, 0xB1, 0xF, 0xF, false)));   // quad_perm [1,0,3,2]
     x = __float_as_int(v);
     return fminf(v, __int_as_float(__builtin_amdgcn_update_dpp(x, x, 0x4E, 0xF, 0xF, false)));   // quad_perm [2,3,0,1]
+#endif
 }
 
 // ctr points at the node inside the LDS tile; returns this lane's share of RHS(node)
