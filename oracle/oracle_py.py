@@ -218,12 +218,26 @@ class OraclePlanner:
 
     def start_key(self):
         """the reference's max_start_key (first component): over the start elements that are reached"""
-        g, k1 = self.g(), self.key1()
+        g, rhs, k1 = self.g(), self.rhs(), self.key1()
         if self.start is None:
             return np.inf
         cx, cy = _roundf(self.start[0]), _roundf(self.start[1])
         elems = [(cx, cy)] if self.algo == ALGO_DFM else [(cx, cy), (cx + 1, cy), (cx, cy + 1), (cx + 1, cy + 1)]
-        ks = [k1[x, y] for x, y in elems if 0 <= x < g.shape[0] and 0 <= y < g.shape[1] and np.isfinite(self.rhs()[x, y])]
+        ks = []
+        for x, y in elems:
+            if 0 <= x < g.shape[0] and 0 <= y < g.shape[1] and np.isfinite(rhs[x, y]):
+                # calculate_key uses min(g, rhs): a start corner may end with G = inf and a finite, final RHS
+                # (FieldDPlanner_impl.h:165-186, 225-256); k1 is built on G, so rebuild it on RHS there
+                k = k1[x, y] if g[x, y] <= rhs[x, y] else np.float32(k1[x, y] - g[x, y] + rhs[x, y]) if np.isfinite(g[x, y]) else None
+                if k is None:
+                    dist = 0.0
+                    if self.use_heuristic:
+                        sx, sy = self.start
+                        if self.algo == ALGO_DFM:
+                            sx, sy = float(_roundf(sx)), float(_roundf(sy))
+                        dist = float(np.hypot(np.float32(sx) - np.float32(x), np.float32(sy) - np.float32(y)))
+                    k = np.float32(rhs[x, y] + np.float32(self.hm) * np.float32(dist))
+                ks.append(k)
         return max(ks) if ks else np.inf
 
     def trusted_mask(self, below_start_key=False):

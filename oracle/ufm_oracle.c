@@ -61,6 +61,7 @@ struct orc_planner {
     int start_nodes[4];
     int n_start_nodes;
     int start_set;
+    int runaway;   /* the last plan() hit expansion_cap() */
 };
 
 /* ---------------- keys: std::pair lexicographic / float --------------- */
@@ -465,6 +466,11 @@ static float elem_min_rhs0(const orc_t *p, int x, int y) {
 
 /* plan<0>: FieldDPlanner_impl.h:23-66, ShiftedGridPlanner_impl.h:17-60,
  * DynamicFastMarching_impl.h:13-54 */
+/* Safety net of the TEST INFRASTRUCTURE, not of the algorithm: the reference's loop has no bound, and
+ * with DFM's upwind quadratic -- not monotone at the ulp level -- an element can flip between over-
+ * and under-consistent for ever on noise-like maps (seen: 432x113 white noise, 20 % obstacles).  A
+ * step that expands more than 256 x the number of elements stops and orc_step returns -75. */
+static unsigned long expansion_cap(const orc_t *p) { return 256ul * (unsigned long)p->n + 100000ul; }
 static void plan0(orc_t *p) {
     unsigned long expanded = 0;
     const int goal = goal_elem(p);
@@ -473,7 +479,7 @@ static void plan0(orc_t *p) {
     while (p->hn > 0 && !(p->algo == ORC_ALGO_DFM ? end_condition_dfm(p) : end_condition_node(p))) {
         int s = p->heap[0];
         pq_pop(p);
-        ++expanded;
+        if (++expanded > expansion_cap(p)) { p->runaway = 1; break; }
         int sx = s / p->ny, sy = s % p->ny;
         int under = !(p->g[s] > p->rhs[s]);
         p->g[s] = under ? INFINITY : p->rhs[s];
@@ -499,6 +505,7 @@ static void plan12_node(orc_t *p) {
     int bptr = 0;
     for (int i = 0; i < p->n_start_nodes; ++i) find_or_init(p, p->start_nodes[i]);
     while (p->hn > 0 && !end_condition_node(p)) {
+        if (expanded > expansion_cap(p)) { p->runaway = 1; break; }
         int s = p->heap[0];
         ++expanded;
         int sx = s / p->ny, sy = s % p->ny;
@@ -565,6 +572,7 @@ static void plan1_dfm(orc_t *p) {
     int b0, b1;
     find_or_init(p, eidx(p, p->start_cx, p->start_cy));
     while (p->hn > 0 && !end_condition_dfm(p)) {
+        if (expanded > expansion_cap(p)) { p->runaway = 1; break; }
         int s = p->heap[0];
         ++expanded;
         int sx = s / p->ny, sy = s % p->ny;
@@ -774,6 +782,7 @@ int orc_step(orc_t *p) { /* ReplannerBase.h:43-75 */
     }
     double t1 = now_ms();
     p->u_time = (float)(t1 - t0);
+    p->runaway = 0;
     if (p->new_goal || p->initialize_search || p->num_updated > 0) {
         if (p->lvl == 0) plan0(p);
         else if (p->algo == ORC_ALGO_DFM) plan1_dfm(p);
@@ -781,7 +790,7 @@ int orc_step(orc_t *p) { /* ReplannerBase.h:43-75 */
     } else p->num_expanded = 0;
     p->new_goal = p->initialize_search = 0;
     p->p_time = (float)(now_ms() - t1);
-    return ORC_LOOP_OK;
+    return p->runaway ? ORC_LOOP_RUNAWAY : ORC_LOOP_OK;
 }
 
 int orc_field_dims(const orc_t *p, int *nx, int *ny) { *nx = p->nx; *ny = p->ny; return 0; }

@@ -33,6 +33,7 @@ enum { ORC_ALGO_FD = 0, ORC_ALGO_SG = 1, ORC_ALGO_DFM = 2 };
 #define ORC_LOOP_OK 0
 #define ORC_LOOP_FAILURE_NO_GRAPH (-1)
 #define ORC_LOOP_FAILURE_NO_GOAL (-2)
+#define ORC_LOOP_RUNAWAY (-75)   /* safety net of the tests: plan() expanded > 256 x elements (see expansion_cap) */
 
 orc_t *orc_create(int algo, int opt_lvl, int use_heuristic);
 void orc_destroy(orc_t *p);
