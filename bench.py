@@ -66,6 +66,8 @@ def main():
     ap.add_argument("--no-profile", action="store_true", help="skip per-launch HIP event timing")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="collective backend for N > 1 (nccl = RCCL; gloo only to rehearse the control flow, staging through host memory)")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="initialise the process group and run the collectives even with one rank (rehearses the RCCL path on a one-GPU box)")
     args = ap.parse_args()
 
     import torch
@@ -78,9 +80,11 @@ def main():
     # one process per GPU; (a gloo rehearsal on a single-GPU box folds the ranks onto the devices there are)
     dev_index = local_rank % max(1, torch.cuda.device_count())
     torch.cuda.set_device(dev_index)
-    if world > 1:
+    if world > 1 or args.force_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if world == 1:
+            os.environ.setdefault("MASTER_PORT", "29511"); os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
         if args.backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
         else:

@@ -70,6 +70,14 @@ constexpr int NTHR = 1024;     // 16 waves; four lanes per node, each wave owns 
 #ifndef UFM_LONG_SWEEPS
 #define UFM_LONG_SWEEPS 8      // a visit that took at least this many sweeps per wave counts as long
 #endif
+#ifndef UFM_LDS_FENCE
+#define UFM_LDS_FENCE 0        // 1: workgroup-scope release fence between a sweep's value write and its wake bits
+#endif
+#if UFM_LDS_FENCE
+#define UFM_SWEEP_FENCE() __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup")
+#else
+#define UFM_SWEEP_FENCE() asm volatile("" ::: "memory")
+#endif
 #ifndef UFM_IDLE_SLEEP
 #define UFM_IDLE_SLEEP 4
 #endif
@@ -611,10 +619,14 @@ __global__ __launch_bounds__(NTHR, UFM_RELAX_WAVES) void k_relax(DevParams P, in
                     if (!(bits & (1 << j))) continue;    // wave-uniform
                     float *ctr = Gs + off[j];
                     bool again = true;
+                    asm volatile("" ::: "memory");
+                    // the node's own value lives in a register during a burst: only this quad writes it, so
+                    // re-reading it from LDS after the evaluation only put a second LDS round trip on the
+                    // dependent chain of every sweep
+                    float g = ctr[0];
                     for (int b = 0; b < 16 && again; ++b) {
                         asm volatile("" ::: "memory");   // re-read the LDS tile every sweep (other waves and lanes write it)
                         float nv = quad_min(eval_quad<ALGO>(ctr, q, C[j]));
-                        const float g = ctr[0];
                         if (goal[j]) nv = 0.0f;          // RHS(goal) = 0, *_impl.h init()
                         int want, doit;
                         if (MODE == MODE_LOWER) {
@@ -634,9 +646,14 @@ __global__ __launch_bounds__(NTHR, UFM_RELAX_WAVES) void k_relax(DevParams P, in
                             nv = INFINITY;
                         }
                         if (doit && q == 0) ctr[0] = nv;
+                        g = doit ? nv : g;
                         const unsigned long long mask = __ballot(doit);
                         const unsigned long long deferred = __ballot(want && !doit);
-                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // value before wake bit
+                        // value before wake bit: the LDS executes the DS instructions of one wave in issue order,
+                        // so the ds_write above is performed before the ds_or below without waiting for it
+                        // (a workgroup-scope release fence costs an s_waitcnt lgkmcnt(0) = one more LDS round
+                        // trip per sweep); the compiler only has to keep the order
+                        UFM_SWEEP_FENCE();
                         if ((mask & wake_sel) != 0ull && wbit[j] && lane != 4)
                             __hip_atomic_fetch_or(&s_wake[wword[j]], wbit[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                         ++cnt[j];
