@@ -81,7 +81,16 @@ constexpr int NTHR = 1024;     // 16 waves; four lanes per node, each wave owns 
 #ifndef UFM_IDLE_SLEEP
 #define UFM_IDLE_SLEEP 4
 #endif
-constexpr int GPAD = 32;       // left padding (floats) so tile rows start 128-B aligned
+// HBM layout of the field: tile-major.  A tile's T x T values are contiguous
+// (1 KB for T = 16: eight 128-B lines); next to them every tile keeps a *ring*: copies of the border
+// values of its eight neighbours (top row, bottom row, left column, right column, four corners --
+// contiguous, three lines), which the neighbours' visits keep up to date when they write their own
+// borders back.  A visit therefore reads tile + ring + cost window = 14 lines where the row-major
+// layout touched ~60 (two lines per field row, one or two per cost row).
+constexpr int TT = T * T;                                        // floats per tile
+constexpr int RING = (4 * T + 4 + 31) / 32 * 32;                 // floats per ring record (4T+4 used)
+constexpr int RING_TOP = 0, RING_BOT = T, RING_LEFT = 2 * T, RING_RIGHT = 3 * T, RING_CORNER = 4 * T;   // corner order: TL TR BL BR
+constexpr int CTS = ((T + 1) * (T + 1) + 127) / 128 * 128;       // bytes per cost-window record
 constexpr float SQRT2F = 1.41421356237309504880168872420969807856967187537694f;  // Macros.cpp:2
 
 enum { MODE_LOWER = 0, MODE_RAISE = 1 };
@@ -122,9 +131,12 @@ struct DevCounters {
 };
 
 struct DevParams {
-    float *G;                   // [nmaps][rows][pitch], +inf padded
-    float *Gprev;               // snapshot of a tile at its first touch in a step
-    uint8_t *cost;              // [nmaps][L][W]
+    float *G;                   // [NT][T][T] tile-major; elements of a tile beyond the map stay +inf
+    float *Gprev;               // snapshot of a tile at its first touch in a step (same layout)
+    float *ring;                // [NT][RING] border values of each tile's eight neighbours (+inf where there is none)
+    uint8_t *cost;              // [nmaps][L][W] the raster (Graph::map_)
+    uint8_t *costT;             // [NT][CTS] per tile, the cost bytes its visit needs: cells (x0-1..x0+T-1, y0-1..y0+T-1) of a
+                                // node tile, (x0..x0+T-1, y0..y0+T-1) of a cell tile (DFM), row-major; 255 outside the map
     int *goal;                  // [nmaps][2]
     int *cand;                  // [2 queues][3][NT] queued tiles (global tile ids), ring of three lists
     int *ready;                 // [NT] tiles released by k_triage for the following relax launch
@@ -153,9 +165,9 @@ struct DevParams {
     int EX, EY;                 // elements per map (nodes or cells)
     int L, W;                   // cells per map
     int TX, TY, NTm, NT, nmaps;
-    int pitch;
+    int cells;                  // elements are cells (DFM), not nodes
     int thr;                    // Graph::occupancy_threshold_uchar_
-    size_t gstride;             // floats per map in G
+    size_t gstride;             // floats per map in G (= NTm * T * T)
     size_t cstride;             // bytes per map in cost
     size_t mstride;             // bytes per map in mark
 };
@@ -185,18 +197,21 @@ __device__ __forceinline__ void park_tile(const DevParams &P, int qz, int gt, in
     atomicMin(&P.pprio[qz * P.NT + gt], pbits);
     if (atomicExch(&P.pflag[qz * P.NT + gt], 1) == 0) P.park[(size_t)(qz * 2) * P.NT + atomicAdd(&P.ctr->npark[qz], 1)] = gt;
 }
+// address of element (x, y) of map m in the tile-major field
+__device__ __host__ __forceinline__ size_t gaddr(const DevParams &P, int m, int x, int y) {
+    return ((size_t)m * P.NTm + (size_t)(x / T) * P.TY + (y / T)) * TT + (size_t)(x % T) * T + (y % T);
+}
 // D*-Lite end condition as a bound on useful work (FieldDPlanner_impl.h:225-256,
 // ShiftedGridPlanner_impl.h:355-386, DynamicFastMarching_impl.h:315-320): the largest key
 // among the start elements that have been reached; +inf while none has.
 __device__ __forceinline__ float start_bound(const DevParams &P, int m) {
     float b = 0.0f;
-    const float *Gm = P.G + (size_t)m * P.gstride;
     const float sx = P.spos[2 * m], sy = P.spos[2 * m + 1];
     for (int i = 0; i < 4; ++i) {
         const int e = P.start[4 * m + i];
         if (e < 0) continue;
         const int x = e / P.EY, y = e - x * P.EY;
-        const float g = __hip_atomic_load(&Gm[(size_t)(x + 1) * P.pitch + (y + GPAD)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const float g = __hip_atomic_load(&P.G[gaddr(P, m, x, y)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         // heuristic keys (FD impl:178-186, DFM impl:146-155): first component k + hm * dist(start, s)
         if (g < INFINITY) b = fmaxf(b, g + P.hm * hypotf(sx - (float)x, sy - (float)y));
     }
@@ -398,11 +413,38 @@ __device__ __forceinline__ float eval_quad(const float *ctr, int q, const QuadCo
     }
 }
 
-// Graph::get_cost, Graph.cpp:262-268
-__device__ __forceinline__ float cell_cost(const DevParams &P, const uint8_t *cm, int cx, int cy) {
-    if (cx < 0 || cy < 0 || cx >= P.L || cy >= P.W) return INFINITY;
-    const int c = cm[(size_t)cx * P.W + cy];
-    return (c >= P.thr) ? INFINITY : (float)c;
+// The cost windows (DevParams::costT).  Entry (cr, cc) of tile (tx, ty) is cell (tx*T + cr - off, ty*T + cc - off),
+// off = 1 and T+1 rows for node tiles (a node's four cells), off = 0 and T rows for cell tiles (DFM).
+__device__ __forceinline__ void cost_window_store(const DevParams &P, int m, int cx, int cy, uint8_t v) {
+    const int bx = cx / T, by = cy / T, rx = cx % T, ry = cy % T;
+    if (P.cells) {
+        P.costT[((size_t)m * P.NTm + (size_t)bx * P.TY + by) * CTS + rx * T + ry] = v;
+        return;
+    }
+    // a cell is read by the node tile that holds its lower-right corner nodes and, on a tile edge, by the next one
+#pragma unroll
+    for (int dx = 0; dx < 2; ++dx)
+#pragma unroll
+        for (int dy = 0; dy < 2; ++dy) {
+            if ((dx && rx != T - 1) || (dy && ry != T - 1)) continue;
+            const int tx = bx + dx, ty = by + dy;
+            if (tx >= P.TX || ty >= P.TY) continue;
+            const int cr = dx ? 0 : rx + 1, cc = dy ? 0 : ry + 1;
+            P.costT[((size_t)m * P.NTm + (size_t)tx * P.TY + ty) * CTS + cr * (T + 1) + cc] = v;
+        }
+}
+// all windows of map m from its raster (set_map)
+__global__ void k_cost_windows(DevParams P, int m) {
+    const int crows = P.cells ? T : T + 1, off = P.cells ? 0 : 1, per = crows * crows;
+    const uint8_t *cm = P.cost + (size_t)m * P.cstride;
+    const size_t n = (size_t)P.NTm * per;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const int t = (int)(i / per), e = (int)(i - (size_t)t * per);
+        const int tx = t / P.TY, ty = t - tx * P.TY, cr = e / crows, cc = e - cr * crows;
+        const int cx = tx * T + cr - off, cy = ty * T + cc - off;
+        const bool in = cx >= 0 && cy >= 0 && cx < P.L && cy < P.W;
+        P.costT[((size_t)m * P.NTm + t) * CTS + e] = in ? cm[(size_t)cx * P.W + cy] : (uint8_t)255;
+    }
 }
 
 // ---- the hot kernel ------------------------------------------------------------------------
@@ -529,8 +571,9 @@ __global__ __launch_bounds__(NTHR, UFM_RELAX_WAVES) void k_relax(DevParams P, in
         }
         const int tx = t / P.TY, ty = t - tx * P.TY;
         const int x0 = tx * T, y0 = ty * T;
-        float *Gm = P.G + (size_t)m * P.gstride;
-        const uint8_t *cm = P.cost + (size_t)m * P.cstride;
+        float *Gt = P.G + (size_t)gt * TT;                       // this tile's values (thread tid owns element tid)
+        const float *ring = P.ring + (size_t)gt * RING;          // its neighbours' border values
+        const uint8_t *ct = P.costT + (size_t)gt * CTS;          // its cost window
 
         if (tid == 0) {
             const int seen = atomicAdd(&P.touched[gt], 1);   // visits of this tile in the current step
@@ -541,10 +584,9 @@ __global__ __launch_bounds__(NTHR, UFM_RELAX_WAVES) void k_relax(DevParams P, in
         if (tid < 16) s_wake[tid] = (1 << PPW) - 1;
         if (tid >= 32 && tid < 41) s_bmin[tid - 32] = INFBITS;
 
-        // stage G tile + halo (rows padded by one, columns by GPAD: no bounds checks)
-        const size_t gidx = io_on ? (size_t)(x0 + io_r + 1) * P.pitch + (y0 + io_c + GPAD) : 0;
+        // stage the tile (contiguous) and its halo: the ring record, in this order (RING_*)
         float gl0 = 0.0f;
-        if (io_on) { gl0 = Gm[gidx]; Gs[(io_r + 1) * GP + io_c + 1] = gl0; }
+        if (io_on) { gl0 = Gt[tid]; Gs[(io_r + 1) * GP + io_c + 1] = gl0; }
         {   // halo: the last 4T+4 threads of the workgroup (for T = 16 they are otherwise idle here)
             const int ht = tid - (NTHR - (4 * T + 4));
             if (ht >= 0) {
@@ -554,13 +596,15 @@ __global__ __launch_bounds__(NTHR, UFM_RELAX_WAVES) void k_relax(DevParams P, in
                 else if (ht < 3 * T) { hr = ht - 2 * T; hc = -1; }
                 else if (ht < 4 * T) { hr = ht - 3 * T; hc = T; }
                 else { hr = (ht & 2) ? T : -1; hc = (ht & 1) ? T : -1; }
-                Gs[(hr + 1) * GP + hc + 1] = Gm[(size_t)(x0 + hr + 1) * P.pitch + (y0 + hc + GPAD)];
+                Gs[(hr + 1) * GP + hc + 1] = ring[ht];
             }
         }
-        // stage the cost tile as float (inf = obstacle / outside)
+        // stage the cost window as float (inf = obstacle / outside: Graph::get_cost, Graph.cpp:262-268)
         for (int e = tid; e < CROWS * CROWS; e += NTHR) {
             const int cr = e / CROWS, cc = e - cr * CROWS;
-            Cs[cr * CP + cc] = cell_cost(P, cm, x0 + cr - COFF, y0 + cc - COFF);
+            const int cx = x0 + cr - COFF, cy = y0 + cc - COFF;
+            const int c = ct[e];
+            Cs[cr * CP + cc] = (cx < 0 || cy < 0 || cx >= P.L || cy >= P.W || c >= P.thr) ? INFINITY : (float)c;
         }
         __syncthreads();
         UFM_TICK(tk1);
@@ -569,7 +613,7 @@ __global__ __launch_bounds__(NTHR, UFM_RELAX_WAVES) void k_relax(DevParams P, in
         const int dbg_rank = P.rank[gt];
         const int dbg_ninf0 = __syncthreads_count(io_on && gl0 == INFINITY);
 #endif
-        if (s_misc[0] && io_on) P.Gprev[(size_t)m * P.gstride + gidx] = gl0;
+        if (s_misc[0] && io_on) P.Gprev[(size_t)gt * TT + tid] = gl0;
 
         // per-lane constants of the wave's four patches
         QuadConsts<ALGO> C[PPW];
@@ -702,7 +746,16 @@ __global__ __launch_bounds__(NTHR, UFM_RELAX_WAVES) void k_relax(DevParams P, in
         // write back what changed; note which neighbours saw their halo change
         const float gf = io_on ? Gs[(io_r + 1) * GP + io_c + 1] : gl0;
         if (gf != gl0) {
-            Gm[gidx] = gf;
+            Gt[tid] = gf;
+            {   // a border value also lives in the rings of the neighbours it borders
+                const int er_ = (io_r == 0) ? -1 : ((io_r == T - 1) ? 1 : 0);
+                const int ec_ = (io_c == 0) ? -1 : ((io_c == T - 1) ? 1 : 0);
+                const bool rok = er_ && tx + er_ >= 0 && tx + er_ < P.TX, cok = ec_ && ty + ec_ >= 0 && ty + ec_ < P.TY;
+                if (rok) P.ring[(size_t)(gt + er_ * P.TY) * RING + (er_ < 0 ? RING_BOT : RING_TOP) + io_c] = gf;
+                if (cok) P.ring[(size_t)(gt + ec_) * RING + (ec_ < 0 ? RING_RIGHT : RING_LEFT) + io_r] = gf;
+                if (rok && cok)   // my corner (er_, ec_) is the opposite corner of the diagonal neighbour's halo
+                    P.ring[(size_t)(gt + er_ * P.TY + ec_) * RING + RING_CORNER + (er_ < 0 ? 2 : 0) + (ec_ < 0 ? 1 : 0)] = gf;
+            }
             // DFM only: the float fixed point of the upwind quadratic is not unique;
             // neighbouring tiles can push each other's border values up one ulp at a time for tens of
             // thousands of launches.  An INCREASE of at most 4 ulp (a rounding-level correction, never
@@ -892,7 +945,7 @@ __device__ __forceinline__ void patch_apply(const DevParams &P, int m, const uin
     const uint8_t nv = patch[e];
     const uint8_t ch = cm[ci] != nv;
     pmask[e] = ch;
-    if (ch) cm[ci] = nv;
+    if (ch) { cm[ci] = nv; cost_window_store(P, m, x + i, y + j, nv); }
 }
 __global__ void k_patch_apply(DevParams P, int m, const uint8_t *patch, uint8_t *pmask, int x, int y, int w, int h) {
     patch_apply(P, m, patch, pmask, x, y, w, h, blockIdx.x * blockDim.x + threadIdx.x);
@@ -1103,6 +1156,14 @@ __global__ void k_start_bound(DevParams P) {
     const int m = blockIdx.x * blockDim.x + threadIdx.x;
     if (m < P.nmaps) P.bnd[m] = start_bound(P, m);
 }
+// window [x0, x0+nx) x [y0, y0+ny) of map m's field, dense row-major (ufm_read_field)
+__global__ void k_gather_field(DevParams P, int m, int x0, int y0, int nx, int ny, float *out) {
+    const size_t n = (size_t)nx * ny;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const int r = (int)(i / ny), c = (int)(i - (size_t)r * ny);
+        out[i] = P.G[gaddr(P, m, x0 + r, y0 + c)];
+    }
+}
 // mean traversable cost of a raster (sets the default ordering band)
 __global__ void k_cost_stats(const uint8_t *cm, size_t n, int thr, unsigned long long *out) {
     unsigned long long s = 0, c = 0;
@@ -1116,12 +1177,9 @@ __global__ void k_cost_stats(const uint8_t *cm, size_t n, int thr, unsigned long
 // count elements whose G differs from the snapshot taken at first touch; release the tiles
 __device__ __forceinline__ void finalize_tiles(const DevParams &P) {
     const int n = P.ctr->tcount;
-    const int io_r = threadIdx.x / T, io_c = threadIdx.x % T;
     for (int i = blockIdx.x; i < n; i += gridDim.x) {
         const int gt = P.tlist[i];
-        const int m = gt / P.NTm, t = gt - m * P.NTm;
-        const int tx = t / P.TY, ty = t - tx * P.TY;
-        const size_t gidx = (size_t)m * P.gstride + (size_t)(tx * T + io_r + 1) * P.pitch + (ty * T + io_c + GPAD);
+        const size_t gidx = (size_t)gt * TT + threadIdx.x;
         const int diff = (threadIdx.x < T * T) && (P.G[gidx] != P.Gprev[gidx]);
         const int c = __syncthreads_count(diff);
         if (threadIdx.x == 0) {
@@ -1256,6 +1314,8 @@ struct Engine {
     uint8_t *d_patch = nullptr;      // staging for host patches
     size_t d_patch_cap = 0;
     uint8_t *h_patch = nullptr;      // pinned staging
+    float *d_field = nullptr;        // ufm_read_field: the requested window, dense
+    size_t d_field_cap = 0;
     uint8_t *d_pmask = nullptr;      // changed-cell mask of the patch being applied
     size_t d_pmask_cap = 0;
     PathJob *d_jobs = nullptr, *h_jobs = nullptr;     // path extraction: per-map start / goal (h_: pinned)
@@ -1297,7 +1357,7 @@ struct Engine {
 
 void Engine::release() {
     if (!allocated) return;
-    hipFree(P.G); hipFree(P.Gprev); hipFree(P.cost); hipFree(P.goal); hipFree(P.cand); hipFree(P.ready); hipFree(P.hint); hipFree(P.rank); hipFree(P.park); hipFree(P.pflag); hipFree(P.pprio); hipFree(P.queued); hipFree(P.prio); hipFree(P.start); hipFree(P.bnd); hipFree(P.spos);
+    hipFree(P.G); hipFree(P.Gprev); hipFree(P.ring); hipFree(P.cost); hipFree(P.costT); hipFree(P.goal); hipFree(P.cand); hipFree(P.ready); hipFree(P.hint); hipFree(P.rank); hipFree(P.park); hipFree(P.pflag); hipFree(P.pprio); hipFree(P.queued); hipFree(P.prio); hipFree(P.start); hipFree(P.bnd); hipFree(P.spos);
     hipFree(P.touched); hipFree(P.tlist); hipFree(P.sflag); hipFree(P.slist); hipFree(P.slist2);
     hipFree(P.mark); hipFree(P.num_updated); hipFree(P.consume); hipFree(P.lmax); hipFree(P.ctr);
     hipFree(d_scratch);
@@ -1316,15 +1376,17 @@ int Engine::alloc(int width, int length) {
     P.NTm = P.TX * P.TY;
     P.nmaps = nmaps;
     P.NT = P.NTm * nmaps;
-    P.pitch = P.TY * T + 2 * GPAD;
-    P.gstride = (size_t)(P.TX * T + 2) * P.pitch;
+    P.cells = nodes ? 0 : 1;
+    P.gstride = (size_t)P.NTm * TT;
     P.cstride = (size_t)L * W;
     P.mstride = (size_t)P.EX * P.EY;
     P.thr = thr_uchar;
     const size_t gbytes = P.gstride * nmaps * sizeof(float);
     HIPCHK(hipMalloc(&P.G, gbytes));
     HIPCHK(hipMalloc(&P.Gprev, gbytes));
+    HIPCHK(hipMalloc(&P.ring, (size_t)P.NT * RING * sizeof(float)));
     HIPCHK(hipMalloc(&P.cost, P.cstride * nmaps));
+    HIPCHK(hipMalloc(&P.costT, (size_t)P.NT * CTS));
     HIPCHK(hipMalloc(&P.goal, sizeof(int) * 2 * nmaps));
     HIPCHK(hipMalloc(&P.cand, sizeof(int) * 6 * P.NT));
     HIPCHK(hipMalloc(&P.ready, sizeof(int) * P.NT));
@@ -1364,6 +1426,7 @@ int Engine::alloc(int width, int length) {
     HIPCHK(hipMemsetAsync(P.goal, 0xFF, sizeof(int) * 2 * nmaps, stream));
     k_fill<<<1024, 256, 0, stream>>>(P.G, P.gstride * nmaps, INFINITY);
     k_fill<<<1024, 256, 0, stream>>>(P.Gprev, P.gstride * nmaps, INFINITY);
+    k_fill<<<1024, 256, 0, stream>>>(P.ring, (size_t)P.NT * RING, INFINITY);
     HIPCHK(hipGetLastError());
     pending.clear();
     for (auto &ms : maps) { ms.have_map = false; ms.initialize_search = true; }
@@ -1620,6 +1683,7 @@ int Engine::step(ufm_stats *out) {
             goals[2 * m] = ms.goal_elem_valid ? ms.goal_ex : -1;
             goals[2 * m + 1] = ms.goal_elem_valid ? ms.goal_ey : -1;
             k_fill<<<1024, 256, 0, stream>>>(P.G + (size_t)m * P.gstride, P.gstride, INFINITY);
+            k_fill<<<256, 256, 0, stream>>>(P.ring + (size_t)m * P.NTm * RING, (size_t)P.NTm * RING, INFINITY);
             if (ms.goal_elem_valid) init_tiles[n_init++] = m * P.NTm + (ms.goal_ex / T) * P.TY + (ms.goal_ey / T);
             else ++n_init;   // nothing reachable: field stays +inf
         } else if (ms.new_start) {
@@ -1959,6 +2023,7 @@ int engine_destroy(Engine *e) {
     for (hipEvent_t v : e->ev) hipEventDestroy(v);
     if (e->d_patch) hipFree(e->d_patch);
     if (e->d_pmask) hipFree(e->d_pmask);
+    if (e->d_field) hipFree(e->d_field);
     if (e->d_jobs) hipFree(e->d_jobs);
     if (e->h_jobs) hipHostFree(e->h_jobs);
     if (e->d_path) hipFree(e->d_path);
@@ -1986,6 +2051,7 @@ int engine_set_map(Engine *e, int m, const uint8_t *src, bool on_device, int wid
     }
     HIPCHK(hipMemcpyAsync(e->P.cost + (size_t)m * e->P.cstride, src, (size_t)width * length,
                           on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, e->stream));
+    k_cost_windows<<<2048, 256, 0, e->stream>>>(e->P, m);
     {   // mean traversable cost -> default ordering band
         unsigned long long *d_acc = reinterpret_cast<unsigned long long *>(e->d_scratch);
         HIPCHK(hipMemsetAsync(d_acc, 0, 2 * sizeof(unsigned long long), e->stream));
@@ -2037,11 +2103,18 @@ int engine_read_field(Engine *e, int m, int x0, int y0, int nx, int ny, float *g
     if (!e || m < 0 || m >= e->nmaps || !e->allocated) return UFM_ERR_INVALID;
     if (x0 < 0 || y0 < 0 || nx <= 0 || ny <= 0 || x0 + nx > e->P.EX || y0 + ny > e->P.EY) return UFM_ERR_INVALID;
     HIPCHK(hipSetDevice(e->device));
-    const float *src = e->P.G + (size_t)m * e->P.gstride + (size_t)(x0 + 1) * e->P.pitch + (y0 + GPAD);
     float *dst = g ? g : rhs;
     if (!dst) return UFM_OK;
-    HIPCHK(hipMemcpy2DAsync(dst, (size_t)ny * sizeof(float), src, (size_t)e->P.pitch * sizeof(float),
-                            (size_t)ny * sizeof(float), (size_t)nx, hipMemcpyDeviceToHost, e->stream));
+    // the field is tile-major on the device: gather the window into a dense buffer, then one copy
+    const size_t n = (size_t)nx * ny;
+    if (n > e->d_field_cap) {
+        if (e->d_field) { HIPCHK(hipStreamSynchronize(e->stream)); hipFree(e->d_field); e->d_field = nullptr; e->d_field_cap = 0; }
+        HIPCHK(hipMalloc(&e->d_field, n * sizeof(float)));
+        e->d_field_cap = n;
+    }
+    k_gather_field<<<(unsigned)std::min<size_t>((n + 255) / 256, 65535), 256, 0, e->stream>>>(e->P, m, x0, y0, nx, ny, e->d_field);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(dst, e->d_field, n * sizeof(float), hipMemcpyDeviceToHost, e->stream));
     HIPCHK(hipStreamSynchronize(e->stream));
     // at the fixed point RHS(s) = F(G)(s) = G(s) for every element (goal: 0 = 0)
     if (g && rhs) std::memcpy(rhs, g, (size_t)nx * ny * sizeof(float));
@@ -2078,7 +2151,7 @@ int engine_extract_path(Engine *e, int max_steps, int lookahead, int allow_indir
     HIPCHK(hipMemcpyAsync(e->d_jobs, e->h_jobs, sizeof(PathJob) * n, hipMemcpyHostToDevice, e->stream));
     PathField F{};
     F.G = e->P.G; F.cost = e->P.cost;
-    F.EX = e->P.EX; F.EY = e->P.EY; F.L = e->P.L; F.W = e->P.W; F.pitch = e->P.pitch; F.thr = e->P.thr;
+    F.EX = e->P.EX; F.EY = e->P.EY; F.L = e->P.L; F.W = e->P.W; F.TY = e->P.TY; F.thr = e->P.thr;
     F.cells = (e->algo == UFM_ALGO_DFM); F.indirect = allow_indirect != 0;
     k_extract_path<<<n, 64, 0, e->stream>>>(F, e->P.gstride, e->P.cstride, e->d_jobs, e->d_path, ostride,
                                             dev_pts, dev_cst, lookahead != 0, max_steps);
@@ -2113,7 +2186,7 @@ int engine_read_info(Engine *e, int m, int x0, int y0, int nx, int ny, int32_t *
     HIPCHK(hipMalloc(&d_out, n * 2 * sizeof(int32_t)));
     PathField F{};
     F.G = e->P.G + (size_t)m * e->P.gstride; F.cost = e->P.cost + (size_t)m * e->P.cstride;
-    F.EX = e->P.EX; F.EY = e->P.EY; F.L = e->P.L; F.W = e->P.W; F.pitch = e->P.pitch; F.thr = e->P.thr;
+    F.EX = e->P.EX; F.EY = e->P.EY; F.L = e->P.L; F.W = e->P.W; F.TY = e->P.TY; F.thr = e->P.thr;
     F.cells = (e->algo == UFM_ALGO_DFM); F.indirect = (e->algo == UFM_ALGO_FD);   // FD: all five cost cases; SG: B / II / A
     k_info<<<(unsigned)((n + 255) / 256), 256, 0, e->stream>>>(F, e->opt_lvl, x0, y0, nx, ny, d_out);
     hipError_t err = hipGetLastError();

@@ -15,9 +15,9 @@
 #pragma once
 
 struct PathField {
-    const float *G;        // this map's field, element (x,y) at (x+1)*pitch + y + GPAD
+    const float *G;        // this map's field, tile-major: element (x,y) in tile (x/T, y/T) of TY per row, T*T floats each
     const uint8_t *cost;   // this map's raster [L][W]
-    int EX, EY, L, W, pitch, thr;
+    int EX, EY, L, W, TY, thr;
     int cells;             // cell-centred field (DFM): node values are 4-cell averages
     int indirect;          // allow_indirect_traversals
 };
@@ -41,7 +41,7 @@ __device__ __forceinline__ float cath_rn(float a, float b) { return sqrt_rn(a * 
 
 __device__ __forceinline__ float field_at(const PathField &F, int x, int y) {      // ExpandedMap::get_rhs
     if (x < 0 || y < 0 || x >= F.EX || y >= F.EY) return INFINITY;
-    return F.G[(size_t)(x + 1) * F.pitch + (y + GPAD)];
+    return F.G[((size_t)(x / T) * F.TY + (y / T)) * (T * T) + (size_t)(x % T) * T + (y % T)];
 }
 // ExpandedMap::get_interp_rhs (ExpandedMap_impl.h:87-97); summation order of the cell variant:
 // (x,y-1) + (x-1,y-1) + (x,y) + (x-1,y)
