@@ -672,7 +672,7 @@ __global__ __launch_bounds__(NTHR, UFM_RELAX_WAVES) void k_relax(DevParams P, in
                         asm volatile("" ::: "memory");   // re-read the LDS tile every sweep (other waves and lanes write it)
                         float nv = quad_min(eval_quad<ALGO>(ctr, q, C[j]));
                         if (goal[j]) nv = 0.0f;          // RHS(goal) = 0, *_impl.h init()
-                        int want, doit;
+                        bool want, doit;
                         if (MODE == MODE_LOWER) {
                             want = (nv != g);            // replace semantics: G <- F(G)
                             // DFM: the upwind quadratic is not causal at the ulp level -- elements that feed
@@ -690,9 +690,15 @@ __global__ __launch_bounds__(NTHR, UFM_RELAX_WAVES) void k_relax(DevParams P, in
                             nv = INFINITY;
                         }
                         if (doit && q == 0) ctr[0] = nv;
-                        g = doit ? nv : g;
-                        const unsigned long long mask = __ballot(doit);
-                        const unsigned long long deferred = __ballot(want && !doit);
+                        // the lane masks come from float compares (one v_cmp each): a ballot of a combined
+                        // predicate costs a v_cndmask + v_cmp to rebuild the mask the compare already was
+                        const float gn = doit ? nv : g;
+                        const unsigned long long mask = __builtin_amdgcn_ballot_w64(gn != g);   // = doit
+                        unsigned long long wanted;                                               // lanes not yet settled
+                        if (MODE == MODE_RAISE) wanted = mask;
+                        else if (ALGO == UFM_ALGO_DFM) wanted = __builtin_amdgcn_ballot_w64(want);
+                        else wanted = __builtin_amdgcn_fcmpf(nv, g, 14);   // lanes with nv != g (14 = FCMP_UNE), as a v_cmp into an SGPR pair
+                        g = gn;
                         // value before wake bit: the LDS executes the DS instructions of one wave in issue order,
                         // so the ds_write above is performed before the ds_or below without waiting for it
                         // (a workgroup-scope release fence costs an s_waitcnt lgkmcnt(0) = one more LDS round
@@ -702,7 +708,7 @@ __global__ __launch_bounds__(NTHR, UFM_RELAX_WAVES) void k_relax(DevParams P, in
                             __hip_atomic_fetch_or(&s_wake[wword[j]], wbit[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                         ++cnt[j];
                         ++tot;
-                        again = (mask | deferred) != 0ull;
+                        again = wanted != 0ull;
                     }
                     if (again && lane == 0)              // burst cap: leave the rest to the next take
                         __hip_atomic_fetch_or(&s_wake[w], 1 << j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
