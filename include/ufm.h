@@ -96,6 +96,11 @@ int ufm_field_dims(const ufm_t *p, int *nx, int *ny);
 int ufm_read_field(ufm_t *p, int x0, int y0, int nx, int ny, float *g, float *rhs);
 /* current raster (after patches), row-major [length][width] */
 int ufm_read_map(ufm_t *p, uint8_t *host_map);
+/* Self-check of the engine's HBM layout (no reference counterpart).  The field is stored tile-major;
+ * every tile also keeps copies of its neighbours' border values and of the cost bytes its visits
+ * read.  Counts the copies that differ from their originals -- both must be 0
+ * whenever no step is running. */
+int ufm_check_layout(ufm_t *p, uint64_t *bad_ring_entries, uint64_t *bad_cost_bytes);
 
 /* ---- tuning knobs of the tile scheduler (no reference counterpart; results do not depend
  * on them).  "delta": absolute width of the ordering band in cost units (< 0: automatic);
@@ -156,6 +161,7 @@ int ufm_batch_set_goal(ufm_batch_t *b, int i, float x, float y);
 int ufm_batch_reset(ufm_batch_t *b, int i);
 int ufm_batch_step(ufm_batch_t *b, ufm_stats *stats);
 int ufm_batch_read_field(ufm_batch_t *b, int i, int x0, int y0, int nx, int ny, float *g, float *rhs);
+int ufm_batch_check_layout(ufm_batch_t *b, uint64_t *bad_ring_entries, uint64_t *bad_cost_bytes);
 /* all maps in one launch: path_xy [n_maps][cap_points][2], step_costs [n_maps][cap_costs], info [n_maps] */
 int ufm_batch_extract_path(ufm_batch_t *b, int max_steps, int lookahead, int allow_indirect,
                            float *path_xy, int cap_points, float *step_costs, int cap_costs, ufm_path_info *info);

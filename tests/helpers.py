@@ -54,4 +54,6 @@ def check_parity(o, g, what="", below_start_key=False):
             what, int(ud.max()), float(rel.max()), nbad, n)
     # RHS view: equals G at the fixed point; must agree with the oracle's RHS wherever that is final
     assert np.array_equal(grhs[mask], gg[mask])
+    # the engine's redundant copies (neighbour rings, cost windows) agree with their originals
+    assert g.check_layout() == (0, 0), "%s: layout self-check %r" % (what, g.check_layout())
     return n, nbad

@@ -238,6 +238,7 @@ def test_batch_of_independent_maps():
         a, ref = b.read_field(i)[m], o.g()[m]
         err = np.abs(a.astype(np.float64) - ref)
         assert np.all(err <= 2e-6 * ref), (i, float(err.max()), int(m.sum()))
+    assert b.check_layout() == (0, 0)
     b.close()
 
 

@@ -21,6 +21,7 @@ SYMBOLS = [
     "ufm_batch_set_occupancy_threshold", "ufm_batch_set_map", "ufm_batch_patch_map",
     "ufm_batch_set_start", "ufm_batch_set_goal", "ufm_batch_reset", "ufm_batch_step",
     "ufm_batch_read_field", "ufm_extract_path", "ufm_batch_extract_path", "ufm_read_info",
+    "ufm_check_layout", "ufm_batch_check_layout",
 ]
 
 
@@ -92,6 +93,8 @@ def load_library():
     L.ufm_field_dims.argtypes = [vp, C.POINTER(i), C.POINTER(i)]
     L.ufm_read_field.argtypes = [vp, i, i, i, i, vp, vp]
     L.ufm_read_map.argtypes = [vp, vp]
+    L.ufm_check_layout.argtypes = [vp, vp, vp]
+    L.ufm_batch_check_layout.argtypes = [vp, vp, vp]
     L.ufm_set_param.argtypes = [vp, C.c_char_p, C.c_double]
     L.ufm_set_profiling.argtypes = [vp, i]
     L.ufm_stream.argtypes = [vp]
@@ -246,6 +249,12 @@ class Planner:
         _chk(self.L.ufm_read_map(self.h, m.ctypes.data), "ufm_read_map")
         return m
 
+    def check_layout(self):
+        """(ring entries, cost-window bytes) that differ from the values they copy; (0, 0) when sound"""
+        bad = (C.c_uint64 * 2)()
+        _chk(self.L.ufm_check_layout(self.h, C.addressof(bad), C.addressof(bad) + 8), "ufm_check_layout")
+        return int(bad[0]), int(bad[1])
+
 
 class BatchPlanner:
     """Batch of independent, equally sized map instances on one device."""
@@ -319,3 +328,8 @@ class BatchPlanner:
         g = np.empty((nx, ny), dtype=np.float32)
         _chk(self.L.ufm_batch_read_field(self.h, i, 0, 0, nx, ny, g.ctypes.data, None), "ufm_batch_read_field")
         return g
+
+    def check_layout(self):
+        bad = (C.c_uint64 * 2)()
+        _chk(self.L.ufm_batch_check_layout(self.h, C.addressof(bad), C.addressof(bad) + 8), "ufm_batch_check_layout")
+        return int(bad[0]), int(bad[1])

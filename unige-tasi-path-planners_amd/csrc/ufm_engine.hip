@@ -1170,6 +1170,39 @@ __global__ void k_gather_field(DevParams P, int m, int x0, int y0, int nx, int n
         out[i] = P.G[gaddr(P, m, x0 + r, y0 + c)];
     }
 }
+// Self-check of the layout's redundancy (ufm_check_layout): every ring entry must equal the border
+// value of the neighbour it copies (+inf where there is no neighbour), every cost-window byte the
+// raster cell it copies.  out[0] / out[1]: mismatching ring entries / window bytes.
+__global__ void k_check_layout(DevParams P, unsigned long long *out) {
+    const int crows = P.cells ? T : T + 1, off = P.cells ? 0 : 1;
+    unsigned long long bad_ring = 0, bad_cost = 0;
+    const size_t nr = (size_t)P.NT * (4 * T + 4);
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nr; i += (size_t)gridDim.x * blockDim.x) {
+        const int gt = (int)(i / (4 * T + 4)), h = (int)(i - (size_t)gt * (4 * T + 4));
+        const int m = gt / P.NTm, t = gt - m * P.NTm, tx = t / P.TY, ty = t - tx * P.TY;
+        int hr, hc;   // halo position relative to the tile, as k_relax stages it
+        if (h < T) { hr = -1; hc = h; }
+        else if (h < 2 * T) { hr = T; hc = h - T; }
+        else if (h < 3 * T) { hr = h - 2 * T; hc = -1; }
+        else if (h < 4 * T) { hr = h - 3 * T; hc = T; }
+        else { hr = ((h - 4 * T) & 2) ? T : -1; hc = ((h - 4 * T) & 1) ? T : -1; }
+        const int x = tx * T + hr, y = ty * T + hc;
+        const bool in = x >= 0 && y >= 0 && x < P.TX * T && y < P.TY * T;
+        const float want = in ? P.G[gaddr(P, m, x, y)] : INFINITY;
+        const float have = P.ring[(size_t)gt * RING + h];
+        if (__float_as_int(want) != __float_as_int(have)) ++bad_ring;
+    }
+    const size_t nc = (size_t)P.NT * crows * crows;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nc; i += (size_t)gridDim.x * blockDim.x) {
+        const int gt = (int)(i / (crows * crows)), e = (int)(i - (size_t)gt * crows * crows);
+        const int m = gt / P.NTm, t = gt - m * P.NTm, tx = t / P.TY, ty = t - tx * P.TY;
+        const int cx = tx * T + e / crows - off, cy = ty * T + e % crows - off;
+        if (cx < 0 || cy < 0 || cx >= P.L || cy >= P.W) continue;
+        if (P.costT[(size_t)gt * CTS + e] != P.cost[(size_t)m * P.cstride + (size_t)cx * P.W + cy]) ++bad_cost;
+    }
+    if (bad_ring) atomicAdd(&out[0], bad_ring);
+    if (bad_cost) atomicAdd(&out[1], bad_cost);
+}
 // mean traversable cost of a raster (sets the default ordering band)
 __global__ void k_cost_stats(const uint8_t *cm, size_t n, int thr, unsigned long long *out) {
     unsigned long long s = 0, c = 0;
@@ -2283,6 +2316,22 @@ int ufm_field_dims(const ufm_t *p, int *nx, int *ny) {
     return UFM_OK;
 }
 int ufm_read_field(ufm_t *p, int x0, int y0, int nx, int ny, float *g, float *rhs) { return p ? engine_read_field(p->e, 0, x0, y0, nx, ny, g, rhs) : UFM_ERR_INVALID; }
+static int engine_check_layout(Engine *e, uint64_t *bad_ring, uint64_t *bad_cost) {
+    if (!e || !e->allocated) return UFM_ERR_INVALID;
+    for (const MapState &ms : e->maps) if (!ms.have_map) return UFM_ERR_INVALID;
+    HIPCHK(hipSetDevice(e->device));
+    unsigned long long *d_acc = reinterpret_cast<unsigned long long *>(e->d_scratch);
+    HIPCHK(hipMemsetAsync(d_acc, 0, 2 * sizeof(unsigned long long), e->stream));
+    k_check_layout<<<1024, 256, 0, e->stream>>>(e->P, d_acc);
+    unsigned long long h[2] = {0, 0};
+    HIPCHK(hipMemcpyAsync(h, d_acc, sizeof(h), hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    if (bad_ring) *bad_ring = h[0];
+    if (bad_cost) *bad_cost = h[1];
+    return UFM_OK;
+}
+int ufm_check_layout(ufm_t *p, uint64_t *bad_ring, uint64_t *bad_cost) { return p ? engine_check_layout(p->e, bad_ring, bad_cost) : UFM_ERR_INVALID; }
+int ufm_batch_check_layout(ufm_batch_t *b, uint64_t *bad_ring, uint64_t *bad_cost) { return b ? engine_check_layout(b->e, bad_ring, bad_cost) : UFM_ERR_INVALID; }
 int ufm_read_map(ufm_t *p, uint8_t *host_map) {
     if (!p || !host_map || !p->e->allocated) return UFM_ERR_INVALID;
     HIPCHK(hipSetDevice(p->e->device));
