@@ -23,15 +23,15 @@ def _free_port():
     return p
 
 
-def _episode(rank, world, use_dist):
+def _episode(rank, world, use_dist, pipeline=False):
     import oracle_py as orc
     cost = ufm_amd.synth.cost_map(SEED + 1000 * rank, SIZE, SIZE)
     start, goal = ufm_amd.synth.start_goal(SIZE, SIZE)
     script = list(ufm_amd.synth.replan_script(SEED, SIZE, SIZE, n_patches=NP))
     patches = [torch.from_numpy(s[4].copy()) for s in script] if rank == 0 else None
-    recv = torch.empty((31, 31), dtype=torch.uint8)
+    recv = [torch.empty((31, 31), dtype=torch.uint8) for _ in range(2)]
     ep = ufm_amd.episode
-    stream = ep.PatchStream(patches, recv, dist=dist if use_dist else None, rank=rank)
+    stream = ep.PatchStream(patches, recv, dist=dist if use_dist else None, rank=rank, pipeline=pipeline, count=NP)
     planner = orc.OraclePlanner(orc.ALGO_FD, 1, False)
     planner.set_occupancy_threshold(1)
     seen = []
@@ -43,14 +43,17 @@ def _episode(rank, world, use_dist):
     tot = ep.run_episode(planner, lambda p: p.set_map(cost), start, goal,
                          [(k, s, t, l) for (k, s, t, l, _) in script], stream, apply_patch,
                          lambda p: {"cells": p.num_expanded})
+    stream.close()
     return tot["cells"], seen, stream.broadcasts
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, pipeline):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    cells, seen, nb = _episode(rank, world, True)
+    cells, seen, nb = _episode(rank, world, True, pipeline)
+    cells2, seen2, nb2 = _episode(rank, world, True, pipeline)      # a second episode on the same process group
+    assert cells2 == cells and nb2 == nb
     ref = [s[4] for s in ufm_amd.synth.replan_script(SEED, SIZE, SIZE, n_patches=NP)]
     ok = all(np.array_equal(a, b) for a, b in zip(seen, ref)) and nb == NP
     t = torch.tensor([float(cells), 1.0 if ok else 0.0], dtype=torch.float64)
@@ -61,12 +64,14 @@ def _worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
-def test_two_ranks_broadcast_patches_and_aggregate():
+@pytest.mark.parametrize("pipeline", [False, True])
+def test_two_ranks_broadcast_patches_and_aggregate(pipeline):
+    """pipeline: the broadcast of patch i+1 is issued by a helper thread while replan i runs"""
     world = 2
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, pipeline)) for r in range(world)]
     for p in procs:
         p.start()
     total, oks = q.get(timeout=120)

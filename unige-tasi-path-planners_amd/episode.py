@@ -11,25 +11,58 @@ import time
 
 class PatchStream:
     """Rank 0 holds all patches; `fetch(i)` returns patch i on every rank.  Per-patch views are made
-    once (slicing a tensor costs microseconds, a replan a few hundred)."""
+    once (slicing a tensor costs microseconds, a replan a few hundred).
 
-    def __init__(self, patches, recv_buffer, dist=None, rank=0, sync=None):
+    `pipeline=True` (needs two receive buffers): the stream is a recording, so the broadcast of patch
+    i+1 is issued (asynchronously, from the calling thread) when patch i is handed out and travels
+    while the caller replans with patch i; the consumer waits for it on the device, not on the host.
+    All broadcasts stay inside whatever region the caller times; only the collective's latency
+    leaves the replans' critical path.  (A helper thread issuing the broadcasts was measured and
+    dropped: Python's thread hand-offs cost more than the collective's enqueue they were to hide.)"""
+
+    def __init__(self, patches, recv_buffer, dist=None, rank=0, sync=None, pipeline=False, count=None):
         self.patches = None if patches is None else [patches[i] for i in range(len(patches))]
-        self.recv = recv_buffer         # tensor every other rank receives into
+        self.recv = list(recv_buffer) if isinstance(recv_buffer, (list, tuple)) else [recv_buffer]
         self.dist = dist
         self.rank = rank
         self.sync = sync                # callable making the broadcast result visible to the consumer
         self.broadcasts = 0
+        self.count = count if count is not None else (len(self.patches) if self.patches is not None else None)
+        self.pipeline = bool(pipeline) and dist is not None and len(self.recv) >= 2 and self.count is not None
+        self._inflight = {}             # patch index -> (work handle, buffer)
+
+    def _buffer(self, i):
+        # rank 0 sends straight from its patch store (no staging copy); the others receive into a buffer
+        return self.patches[i] if self.rank == 0 else self.recv[i % len(self.recv)]
+
+    def _issue(self, i):
+        buf = self._buffer(i)
+        self._inflight[i] = (self.dist.broadcast(buf, src=0, async_op=True), buf)
+
+    def close(self):
+        for work, _ in self._inflight.values():
+            work.wait()
+        self._inflight.clear()
 
     def fetch(self, i):
         if self.dist is None:
             return self.patches[i]
-        # rank 0 sends straight from its patch store (no staging copy); the others receive into `recv`
-        buf = self.patches[i] if self.rank == 0 else self.recv
-        self.dist.broadcast(buf, src=0)
+        if not self.pipeline:
+            buf = self._buffer(i)
+            self.dist.broadcast(buf, src=0)
+            self.broadcasts += 1
+            if self.sync is not None:
+                self.sync()
+            return buf
+        if i not in self._inflight:
+            self._issue(i)
+        work, buf = self._inflight.pop(i)
+        work.wait()                     # RCCL: the current stream waits, the host does not; gloo: the host waits
         self.broadcasts += 1
         if self.sync is not None:
             self.sync()
+        if i + 1 < self.count:
+            self._issue(i + 1)          # travels while the caller replans with patch i
         return buf
 
 
