@@ -497,7 +497,8 @@ __global__ __launch_bounds__(NTHR, UFM_RELAX_WAVES) void k_relax(DevParams P, in
     if (tid == 0) s_min = INFBITS;
     if (!DYN && tid < 64) s_B[tid] = (MODE == MODE_LOWER && P.focused && tid < P.nmaps) ? start_bound(P, tid) : INFINITY;
     __syncthreads();
-    if (!DYN) {   // smallest priority among the entries that are not parked beyond their map's start key
+    if (!DYN && MODE == MODE_LOWER) {   // smallest priority among the entries that are not parked beyond their map's start key
+        // (invalidation is order-free -- delta = +inf --: no band, no scan, two dependent loads less per launch)
         int lmin = INFBITS;
         for (int i = tid; i < n; i += NTHR) {
             const int c = cand[i], pb = prio[c], mm = c / P.NTm;
