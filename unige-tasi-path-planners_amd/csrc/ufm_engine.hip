@@ -495,13 +495,17 @@ __global__ __launch_bounds__(NTHR, UFM_RELAX_WAVES) void k_relax(DevParams P, in
     constexpr int COFF = (ALGO == UFM_ALGO_DFM) ? 0 : 1;
 
     if (tid == 0) s_min = INFBITS;
+    // the list -> priority loads of the scan below are issued before the start keys are waited for: the two
+    // chains of dependent loads (start elements -> G, list -> priority) run side by side instead of in series
+    int c_first = 0, pb_first = INFBITS;
+    if (!DYN && MODE == MODE_LOWER && tid < n) { c_first = cand[tid]; pb_first = prio[c_first]; }
     if (!DYN && tid < 64) s_B[tid] = (MODE == MODE_LOWER && P.focused && tid < P.nmaps) ? start_bound(P, tid) : INFINITY;
     __syncthreads();
     if (!DYN && MODE == MODE_LOWER) {   // smallest priority among the entries that are not parked beyond their map's start key
         // (invalidation is order-free -- delta = +inf --: no band, no scan, two dependent loads less per launch)
         int lmin = INFBITS;
         for (int i = tid; i < n; i += NTHR) {
-            const int c = cand[i], pb = prio[c], mm = c / P.NTm;
+            const int c = (i == tid) ? c_first : cand[i], pb = (i == tid) ? pb_first : prio[c], mm = c / P.NTm;
             const float Bm = mm < 64 ? s_B[mm] : INFINITY;
             if (__int_as_float(pb) < Bm || Bm == INFINITY) lmin = min(lmin, pb);
         }
