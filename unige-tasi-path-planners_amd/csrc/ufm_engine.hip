@@ -1356,6 +1356,9 @@ struct Engine {
     hipStream_t stream = nullptr;
     DevCounters *h_ctr = nullptr;    // pinned, host-coherent: k_publish writes it, the host spins on h_flag
     unsigned int *h_flag = nullptr;  // sequence number of the last published copy (same allocation)
+    DevCounters *h_pipe_ctr[2] = {nullptr, nullptr};   // run_phase keeps one batch of launches in flight ahead of the one whose
+    unsigned int *h_pipe_flag[2] = {nullptr, nullptr}; // counters it is looking at: two more published copies, used alternately
+    bool pipeline_batches = true;
     unsigned int pub_seq = 0;
     bool spin_wait = true;           // false: hipMemcpyAsync + hipStreamSynchronize instead
     bool fuse_control = true;        // replans: fused control kernels (k_replan_begin / _raise_to_lower / _end)
@@ -1407,6 +1410,7 @@ struct Engine {
     int launch_relax(int mode, float rbound, hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr);
     int fetch_counters();
     int wait_published();
+    int wait_flag(const unsigned int *flag, unsigned int seq);
     int win_raise[6] = {8, 8, 8, 8, 8, 8}, win_lower[6] = {8, 8, 8, 8, 8, 8}, win_pos = 0;   // launches recent replans needed
     int run_phase(int mode, float rbound, uint32_t *launches, float *kernel_ms, uint32_t *timed);
     int profile_stride = 4;          // profiling: every n-th launch of a plan is bracketed by events
@@ -1542,16 +1546,17 @@ int Engine::fetch_counters() {
     return wait_published();
 }
 // spin until the device has published copy number pub_seq
-int Engine::wait_published() {
+int Engine::wait_published() { return wait_flag(h_flag, pub_seq); }
+int Engine::wait_flag(const unsigned int *flag, unsigned int seq) {
     const auto t0 = std::chrono::steady_clock::now();
     for (unsigned int spins = 1;; ++spins) {
-        if (__atomic_load_n(h_flag, __ATOMIC_ACQUIRE) == pub_seq) return UFM_OK;
+        if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) == seq) return UFM_OK;
         __builtin_ia32_pause();
         // a faulted kernel never publishes: after 20 s ask the runtime what happened
         if ((spins & 0xFFFF) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(20)) break;
     }
     HIPCHK(hipStreamSynchronize(stream));
-    return __atomic_load_n(h_flag, __ATOMIC_ACQUIRE) == pub_seq ? UFM_OK : UFM_ERR_HIP_BASE;
+    return __atomic_load_n(flag, __ATOMIC_ACQUIRE) == seq ? UFM_OK : UFM_ERR_HIP_BASE;
 }
 
 // one relax launch over a short queue (fused triage) with an explicit launch-index argument
@@ -1650,11 +1655,65 @@ int Engine::launch_relax(int mode, float rbound, hipEvent_t e0, hipEvent_t e1) {
 // costs a few microseconds, a host round trip more).
 // A phase also ends when a launch released nothing: everything still queued lies beyond the bound
 // (the start's key) and stays queued for a later step.
+// The host does not wait for a batch before it submits the next one: while it reads the counters batch
+// b published, batch b+1 is already running (a host round trip -- publish, PCIe, decision, first
+// dispatch -- left the GPU idle for ~15 us, 68 times per 4096^2 plan).  The price: when batch b turns
+// out to have drained the queue, batch b+1 consists of launches that find nothing to do (a few us each).
 int Engine::run_phase(int mode, float rbound, uint32_t *launches, float *kernel_ms, uint32_t *timed) {
     const int q = (mode == MODE_LOWER) ? Q_LOWER : Q_RAISE;
     int batch = batch_fixed > 0 ? batch_fixed : 4;
     const long cap = 64L * (P.TX + P.TY) * T + 4096;   // generous bound on sweeps
     long total = 0;
+    if (spin_wait && pipeline_batches && h_pipe_ctr[0]) {
+        struct InFlight { unsigned int seq; int slot, ns, iter_after; };
+        constexpr int EVSLOT = 64;                      // events per slot: a batch has at most 32 launches
+        while (profiling && ev.size() < (size_t)(4 + 2 * EVSLOT)) { hipEvent_t a; HIPCHK(hipEventCreate(&a)); ev.push_back(a); }
+        auto collect = [&](const InFlight &f) -> int {  // wait for the batch, add its timed launches
+            int rc = wait_flag(h_pipe_flag[f.slot], f.seq);
+            if (rc != UFM_OK) return rc;
+            for (int k = 0; k < f.ns; ++k) {
+                float ms = 0;
+                HIPCHK(hipEventElapsedTime(&ms, ev[4 + f.slot * EVSLOT + 2 * k], ev[4 + f.slot * EVSLOT + 2 * k + 1]));
+                *kernel_ms += ms;
+            }
+            *timed += (uint32_t)f.ns;
+            return UFM_OK;
+        };
+        InFlight prev{}, cur{};
+        bool have_prev = false;
+        int slot = 0;
+        for (;;) {
+            int ns = 0;
+            for (int k = 0; k < batch; ++k) {
+                const bool timed_k = profiling && ((total + k) % profile_stride == 0);
+                const int eb = 4 + slot * EVSLOT + 2 * ns;
+                launch_relax(mode, rbound, timed_k ? ev[eb] : nullptr, timed_k ? ev[eb + 1] : nullptr);
+                if (timed_k) ++ns;
+            }
+            ++pub_seq;
+            k_publish<<<1, 64, 0, stream>>>(P.ctr, h_pipe_ctr[slot], h_pipe_flag[slot], pub_seq);
+            HIPCHK(hipGetLastError());
+            cur = {pub_seq, slot, ns, iter[q]};
+            *launches += (uint32_t)batch;
+            total += batch;
+            if (have_prev) {
+                int rc = collect(prev);
+                if (rc != UFM_OK) return rc;
+                const DevCounters *c = h_pipe_ctr[prev.slot];
+                const int active = c->cnt[q][prev.iter_after % 3];
+                const bool done = active == 0 || c->rel[q][(prev.iter_after + 2) % 3] == 0;   // drained / nothing released: the rest lies beyond the bound
+                if (done || total > cap) {
+                    rc = collect(cur);                  // the batch submitted meanwhile found nothing to do
+                    if (rc != UFM_OK) return rc;
+                    last_active = h_pipe_ctr[cur.slot]->cnt[q][cur.iter_after % 3];
+                    return done ? UFM_OK : UFM_ERR_NOT_CONVERGED;
+                }
+                last_active = active;
+                batch = batch_fixed > 0 ? batch_fixed : (active > 512 ? 32 : (active > 256 ? 16 : (active > 32 ? 8 : 4)));
+            }
+            prev = cur; have_prev = true; slot ^= 1;
+        }
+    }
     for (;;) {
         int ns = 0;   // launches of this batch that are timed: a sample, the event packets cost ~4 us each
         for (int k = 0; k < batch; ++k) {
@@ -2048,6 +2107,13 @@ int engine_create(Engine **out, int n_maps, int algo, int opt_lvl, int use_heuri
         std::memset(pub, 0, flag_off + 64);
         e->h_ctr = static_cast<DevCounters *>(pub);
         e->h_flag = reinterpret_cast<unsigned int *>(static_cast<char *>(pub) + flag_off);
+        for (int i = 0; i < 2; ++i) {
+            void *pp = nullptr;
+            HIPCHK(hipHostMalloc(&pp, flag_off + 64, hipHostMallocMapped | hipHostMallocCoherent));
+            std::memset(pp, 0, flag_off + 64);
+            e->h_pipe_ctr[i] = static_cast<DevCounters *>(pp);
+            e->h_pipe_flag[i] = reinterpret_cast<unsigned int *>(static_cast<char *>(pp) + flag_off);
+        }
         void *job = nullptr;
         HIPCHK(hipHostMalloc(&job, sizeof(ReplanJob), hipHostMallocMapped | hipHostMallocCoherent));
         std::memset(job, 0, sizeof(ReplanJob));
@@ -2092,6 +2158,7 @@ int engine_destroy(Engine *e) {
     if (e->h_patch) hipHostFree(e->h_patch);
     e->drop_graphs();
     if (e->h_ctr) hipHostFree(e->h_ctr);
+    for (int i = 0; i < 2; ++i) if (e->h_pipe_ctr[i]) hipHostFree(e->h_pipe_ctr[i]);
     if (e->h_job) hipHostFree(e->h_job);
     if (e->h_scratch) hipHostFree(e->h_scratch);
     if (e->h_bnd) hipHostFree(e->h_bnd);
@@ -2368,6 +2435,7 @@ int ufm_set_param(ufm_t *p, const char *name, double value) {
     else if (!std::strcmp(name, "delta_scale")) { e->delta_scale = (float)value; e->delta_abs = -1.0f; }
     else if (!std::strcmp(name, "max_iters")) e->max_iters = value < 1 ? 1 : (int)value;
     else if (!std::strcmp(name, "batch")) e->batch_fixed = (int)value;
+    else if (!std::strcmp(name, "pipeline_batches")) e->pipeline_batches = value != 0;
     else if (!std::strcmp(name, "grid")) e->grid_relax = value < 1 ? 1 : (int)value;
     else if (!std::strcmp(name, "small_grid")) e->small_grid = value < 1 ? 1 : (int)value;
     else if (!std::strcmp(name, "dyn_grid")) e->dyn_grid = value < 1 ? 1 : (int)value;
