@@ -1399,6 +1399,9 @@ struct Engine {
                                      // re-queued instead of holding the whole launch (measured optimum on 4096^2)
     float delta_abs = -1.0f;         // ordering band; < 0: delta_scale * T * mean traversable cost
     float delta_scale = 1.5f;
+    float delta_scale_long = 2.0f;   // ... for long queues (the plans' cursor hand-out launches): a wider band, fewer band steps
+                                     // (tools/sweep.py on the final scheduler: plan 24.2 ms at 1.5, 23.6 at 2.0, 23.9 at 2.5;
+                                     //  the replans' short launches are best at 1.5)
     float mean_cost = 1.0f;
     int batch_fixed = 0;
     bool profiling = false;
@@ -1613,11 +1616,11 @@ int Engine::replan_graph(int nr, int nl, float band, hipGraphExec_t *out) {
 // e0 / e1 (profiling): HIP events recorded on the engine's stream right around the relax kernel
 int Engine::launch_relax(int mode, float rbound, hipEvent_t e0, hipEvent_t e1) {
     dim3 g(grid_relax), b(NTHR);
-    // invalidation is order-free; lowering releases tiles in bands of `delta`
-    const float delta = (mode == MODE_RAISE) ? INFINITY : (delta_abs >= 0.0f ? delta_abs : delta_scale * T * mean_cost);
     const int q = (mode == MODE_LOWER) ? Q_LOWER : Q_RAISE;
     // long queue: vectorised triage + balanced hand-out of the released tiles; short queue: fused
     const bool dyn = dynamic_mode && last_active > grid_relax / 4;
+    // invalidation is order-free; lowering releases tiles in bands of `delta`
+    const float delta = (mode == MODE_RAISE) ? INFINITY : (delta_abs >= 0.0f ? delta_abs : (dyn ? delta_scale_long : delta_scale) * T * mean_cost);
     // a short queue (replans: a handful of tiles per launch) does not need the whole chip: a small
     // grid starts, and when there is nothing left to do ends, sooner
     if (!dyn && last_active <= small_grid / 2 && small_grid < grid_relax) g = dim3(small_grid);
@@ -2093,7 +2096,7 @@ int engine_create(Engine **out, int n_maps, int algo, int opt_lvl, int use_heuri
     // scheduling defaults per planner family (tools/sweep.py, 4096^2): DFM's two-stencil operator needs about
     // twice the sweeps per tile; a wider band and an earlier re-queue suit it better (plan 60 -> 52 ms)
     // -- for a single map; a batch is throughput-bound and keeps the less redundant setting (8 x 2048^2: 484 vs 476 M cells/s)
-    if (algo == UFM_ALGO_DFM && n_maps == 1) { e->delta_scale = 2.5f; e->max_iters = 16; }
+    if (algo == UFM_ALGO_DFM && n_maps == 1) { e->delta_scale = e->delta_scale_long = 2.5f; e->max_iters = 16; }
     e->maps.resize(n_maps);
     hipDeviceProp_t prop;
     HIPCHK(hipGetDeviceProperties(&prop, device_id));
@@ -2432,7 +2435,8 @@ int ufm_set_param(ufm_t *p, const char *name, double value) {
     if (!p || !name) return UFM_ERR_INVALID;
     Engine *e = p->e;
     if (!std::strcmp(name, "delta")) e->delta_abs = (float)value;
-    else if (!std::strcmp(name, "delta_scale")) { e->delta_scale = (float)value; e->delta_abs = -1.0f; }
+    else if (!std::strcmp(name, "delta_scale")) { e->delta_scale = e->delta_scale_long = (float)value; e->delta_abs = -1.0f; }
+    else if (!std::strcmp(name, "delta_scale_long")) { e->delta_scale_long = (float)value; e->delta_abs = -1.0f; }
     else if (!std::strcmp(name, "max_iters")) e->max_iters = value < 1 ? 1 : (int)value;
     else if (!std::strcmp(name, "batch")) e->batch_fixed = (int)value;
     else if (!std::strcmp(name, "pipeline_batches")) e->pipeline_batches = value != 0;
