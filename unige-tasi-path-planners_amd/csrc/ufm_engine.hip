@@ -580,6 +580,16 @@ __global__ __launch_bounds__(NTHR, UFM_RELAX_WAVES) void k_relax(DevParams P, in
         const float *ring = P.ring + (size_t)gt * RING;          // its neighbours' border values
         const uint8_t *ct = P.costT + (size_t)gt * CTS;          // its cost window
 
+        // All global loads of the staging are issued first, unconditionally (clamped addresses instead of
+        // branches), then thread 0's bookkeeping atomics, and only then are the results consumed: one memory
+        // round trip in front of the visit.  (Written as guarded blocks -- load, wait, LDS store, each -- the
+        // first waves paid three round trips in series, thread 0's wave up to five.)
+        const int ht = tid - (NTHR - (4 * T + 4));               // halo: the last 4T+4 threads of the workgroup
+        constexpr int CN = CROWS * CROWS;
+        const float gl0 = Gt[io_on ? tid : 0];
+        const float hv = ring[ht >= 0 ? ht : 0];
+        const int c0 = ct[tid < CN ? tid : 0];
+        const int goal_x = P.goal[2 * m], goal_y = P.goal[2 * m + 1];   // (with the rest: read after the barrier they cost two more round trips)
         if (tid == 0) {
             const int seen = atomicAdd(&P.touched[gt], 1);   // visits of this tile in the current step
             const int first = seen == 0;
@@ -589,26 +599,22 @@ __global__ __launch_bounds__(NTHR, UFM_RELAX_WAVES) void k_relax(DevParams P, in
         if (tid < 16) s_wake[tid] = (1 << PPW) - 1;
         if (tid >= 32 && tid < 41) s_bmin[tid - 32] = INFBITS;
 
-        // stage the tile (contiguous) and its halo: the ring record, in this order (RING_*)
-        float gl0 = 0.0f;
-        if (io_on) { gl0 = Gt[tid]; Gs[(io_r + 1) * GP + io_c + 1] = gl0; }
-        {   // halo: the last 4T+4 threads of the workgroup (for T = 16 they are otherwise idle here)
-            const int ht = tid - (NTHR - (4 * T + 4));
-            if (ht >= 0) {
-                int hr, hc;
-                if (ht < T) { hr = -1; hc = ht; }
-                else if (ht < 2 * T) { hr = T; hc = ht - T; }
-                else if (ht < 3 * T) { hr = ht - 2 * T; hc = -1; }
-                else if (ht < 4 * T) { hr = ht - 3 * T; hc = T; }
-                else { hr = (ht & 2) ? T : -1; hc = (ht & 1) ? T : -1; }
-                Gs[(hr + 1) * GP + hc + 1] = ring[ht];
-            }
+        // the tile (contiguous) and its halo: the ring record, in this order (RING_*)
+        if (io_on) Gs[(io_r + 1) * GP + io_c + 1] = gl0;
+        if (ht >= 0) {
+            int hr, hc;
+            if (ht < T) { hr = -1; hc = ht; }
+            else if (ht < 2 * T) { hr = T; hc = ht - T; }
+            else if (ht < 3 * T) { hr = ht - 2 * T; hc = -1; }
+            else if (ht < 4 * T) { hr = ht - 3 * T; hc = T; }
+            else { hr = (ht & 2) ? T : -1; hc = (ht & 1) ? T : -1; }
+            Gs[(hr + 1) * GP + hc + 1] = hv;
         }
-        // stage the cost window as float (inf = obstacle / outside: Graph::get_cost, Graph.cpp:262-268)
-        for (int e = tid; e < CROWS * CROWS; e += NTHR) {
+        // the cost window as float (inf = obstacle / outside: Graph::get_cost, Graph.cpp:262-268)
+        for (int e = tid; e < CN; e += NTHR) {
             const int cr = e / CROWS, cc = e - cr * CROWS;
             const int cx = x0 + cr - COFF, cy = y0 + cc - COFF;
-            const int c = ct[e];
+            const int c = (e == tid) ? c0 : ct[e];
             Cs[cr * CP + cc] = (cx < 0 || cy < 0 || cx >= P.L || cy >= P.W || c >= P.thr) ? INFINITY : (float)c;
         }
         __syncthreads();
@@ -629,7 +635,7 @@ __global__ __launch_bounds__(NTHR, UFM_RELAX_WAVES) void k_relax(DevParams P, in
             const int lx = (wr * PR + j / PR) * 4 + (nd >> 2), ly = (wc * PR + j % PR) * 4 + (nd & 3);
             C[j].load(Cs, lx, ly, q);
             off[j] = (lx + 1) * GP + ly + 1;
-            goal[j] = (x0 + lx == P.goal[2 * m]) && (y0 + ly == P.goal[2 * m + 1]);
+            goal[j] = (x0 + lx == goal_x) & (y0 + ly == goal_y);
             wword[j] = 0; wbit[j] = 0;
             if (lane < 9) {
                 const int gr = wr * PR + j / PR + lane / 3 - 1, gc = wc * PR + j % PR + lane % 3 - 1;   // PT x PT patch grid
