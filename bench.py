@@ -112,6 +112,9 @@ def main():
     planner = ufm_amd.Planner(algo, 1 if algo != ufm_amd.ALGO_SG else 2, False, device=dev_index)
     planner.set_occupancy_threshold(1)
     planner.set_profiling(not args.no_profile)
+    # HIP events on every 16th launch of a plan (~110 timed launches per run): the event packets cost ~4 us each,
+    # with every 4th launch timed the episode was 3 % slower than untimed
+    planner.set_param("profile_stride", 16)
 
     ep = ufm_amd.episode
     # The engine's HIP stream becomes torch's current stream: the collective's completion is then a
@@ -215,7 +218,7 @@ def main():
         if lkms > 0 and llaunch > 0 and ltimed > 0:
             # dominant kernel: k_relax<algo, LOWER>.  Algorithmic bytes = tile visits x (9 B per element
             # + halo) per SURVEY.md 8(d); duration = HIP events on the engine's stream around its launches.
-            # (the events bracket a sample of the launches -- every 4th of a plan, every one of a replan --
+            # (the events bracket a sample of the launches -- every 16th of a plan --
             # so that they can stay on inside the timed region: ltimed of the llaunch launches)
             avg_launch_s = lkms * 1e-3 / ltimed
             achieved = (lvis / llaunch) * BYTES_PER_TILE_VISIT / avg_launch_s / 1e9
