@@ -27,9 +27,9 @@ def bytes_per_tile_visit(tile):
 HBM_PEAK_GBS = 8000.0                                         # MI355X_MICROARCH.md: HBM3E peak
 
 
-def cpu_baseline(size, seed, n_patches):
-    """The oracle (a C port of the reference's D*-Lite FD-1 planner) timed on one host
-    core on a bounded sample of the same workload.  Checker/baseline only."""
+def cpu_baseline(size, seed, n_patches, algo_name="FD", heuristic=False):
+    """The oracle (a C port of the reference's D*-Lite planners; FD-1 for the headline) timed on one
+    host core on a bounded sample of the same workload.  Checker/baseline only."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import oracle_py as orc
     import ufm_amd
@@ -39,8 +39,12 @@ def cpu_baseline(size, seed, n_patches):
         pass
     cost = ufm_amd.synth.cost_map(seed, size, size)
     start, goal = ufm_amd.synth.start_goal(size, size)
-    p = orc.OraclePlanner(orc.ALGO_FD, 1, False)
-    p.reset(); p.set_occupancy_threshold(1); p.set_map(cost); p.set_start(*start); p.set_goal(*goal)
+    oalgo = {"FD": orc.ALGO_FD, "SG": orc.ALGO_SG, "DFM": orc.ALGO_DFM}[algo_name]
+    p = orc.OraclePlanner(oalgo, 2 if algo_name == "SG" else 1, heuristic)
+    p.reset(); p.set_occupancy_threshold(1)
+    if heuristic:
+        p.set_heuristic_multiplier(float(cost.min()))
+    p.set_map(cost); p.set_start(*start); p.set_goal(*goal)
     exp, ms = 0, 0.0
     assert p.step() == 0
     exp += p.num_expanded; ms += p.u_time + p.p_time
@@ -49,8 +53,8 @@ def cpu_baseline(size, seed, n_patches):
         assert p.step() == 0
         exp += p.num_expanded; ms += p.u_time + p.p_time
     return {"value": exp / (ms * 1e-3), "unit": "cells/s", "cores": 1, "kind": "port",
-            "sample": "FD-1 %dx%d seed %d, full plan + %d replans, %d expansions in %.1f s" % (
-                size, size, seed, n_patches, exp, ms * 1e-3)}
+            "sample": "%s-%d%s %dx%d seed %d, full plan + %d replans, %d expansions in %.1f s" % (
+                algo_name, 2 if algo_name == "SG" else 1, " heuristic keys" if heuristic else "", size, size, seed, n_patches, exp, ms * 1e-3)}
 
 
 def main():
@@ -60,7 +64,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--size", type=int, default=4096)
     ap.add_argument("--patches", type=int, default=100)
+    ap.add_argument("--seed", type=int, default=7, help="seed of the synthetic map and patch script (SURVEY 8d: 7 for the headline, 42 for config 5)")
     ap.add_argument("--algo", default="FD", choices=["FD", "SG", "DFM"])
+    ap.add_argument("--heuristic", action="store_true",
+                    help="heuristic keys with hm = the map's smallest cost (planners built without -DNO_HEURISTIC; BASELINE config 5 with --size 8192)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-size", type=int, default=4096, help="map size of the CPU baseline sample (4096 = the identical workload, ~5 s)")
     ap.add_argument("--no-profile", action="store_true", help="skip per-launch HIP event timing")
@@ -95,7 +102,7 @@ def main():
         dist = None
     dev = torch.device("cuda", dev_index)
 
-    size, seed = args.size, 7
+    size, seed = args.size, args.seed
     algo = {"FD": ufm_amd.ALGO_FD, "SG": ufm_amd.ALGO_SG, "DFM": ufm_amd.ALGO_DFM}[args.algo]
     # independent map instance per rank; rank 0's instance is the BASELINE seed
     cost = ufm_amd.synth.cost_map(seed + 1000 * rank, size, size)
@@ -109,7 +116,9 @@ def main():
         d_patches = torch.empty((max(1, len(script)), psz, psz), dtype=torch.uint8, device=dev)
     d_recv = [torch.empty((psz, psz), dtype=torch.uint8, device=dev) for _ in range(2)]
 
-    planner = ufm_amd.Planner(algo, 1 if algo != ufm_amd.ALGO_SG else 2, False, device=dev_index)
+    planner = ufm_amd.Planner(algo, 1 if algo != ufm_amd.ALGO_SG else 2, bool(args.heuristic), device=dev_index)
+    if args.heuristic:
+        planner.set_heuristic_multiplier(float(cost.min()))
     planner.set_occupancy_threshold(1)
     planner.set_profiling(not args.no_profile)
     # HIP events on every 16th launch of a plan (~110 timed launches per run): the event packets cost ~4 us each,
@@ -206,8 +215,9 @@ def main():
             "dtype": "f32",
             "data": "synthetic",
             "config": {
-                "workload": "Field D* level-1, %dx%d cost map (seed 7 generator, SURVEY 8d), full plan + %d 31x31 patches with moving start, one map instance per GPU" % (size, size, len(script)),
-                "algo": args.algo, "size": size, "patches": len(script),
+                "workload": "%s, %dx%d cost map (seed %d generator, SURVEY 8d), full plan + %d 31x31 patches with moving start, one map instance per GPU" % (
+                    {"FD": "Field D* level-1", "SG": "Shifted-Grid FM level-2", "DFM": "MS-DFM level-1"}[args.algo], size, size, seed, len(script)),
+                "algo": args.algo, "size": size, "patches": len(script), "heuristic_keys": bool(args.heuristic),
                 "cells_per_step_rank0": cells / max(1, args.steps),
                 "relax_launches_per_step_rank0": launches / max(1, args.steps),
                 "tile_visits_per_step_rank0": visits / max(1, args.steps),
@@ -236,7 +246,7 @@ def main():
                 "note": "latency-bound (dependent in-LDS sweeps along the wavefront), not bandwidth-bound: see DESIGN.md",
             }
         if not args.no_cpu_baseline and world == 1:   # the CPU baseline is reported at N = 1 only
-            out["cpu_baseline"] = cpu_baseline(args.cpu_size, seed, args.patches)
+            out["cpu_baseline"] = cpu_baseline(args.cpu_size, seed, args.patches, args.algo, bool(args.heuristic))
         print(json.dumps(out))
     stream.close()
     if dist is not None:
