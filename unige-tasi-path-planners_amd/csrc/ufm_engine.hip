@@ -71,7 +71,9 @@ constexpr int NTHR = 1024;     // 16 waves; four lanes per node, each wave owns 
 #define UFM_LONG_SWEEPS 8      // a visit that took at least this many sweeps per wave counts as long
 #endif
 #ifndef UFM_LDS_FENCE
-#define UFM_LDS_FENCE 0        // 1: workgroup-scope release fence between a sweep's value write and its wake bits
+#define UFM_LDS_FENCE 1        // 1: workgroup-scope release fence between a sweep's value write and its wake bits
+                               // (0: compiler-only ordering, relying on the LDS executing one wave's DS instructions in
+                               //  issue order -- all tests pass and nothing measurable is gained, so the fence stays)
 #endif
 #if UFM_LDS_FENCE
 #define UFM_SWEEP_FENCE() __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup")
@@ -710,11 +712,7 @@ __global__ __launch_bounds__(NTHR, UFM_RELAX_WAVES) void k_relax(DevParams P, in
                         else if (ALGO == UFM_ALGO_DFM) wanted = __builtin_amdgcn_ballot_w64(want);
                         else wanted = __builtin_amdgcn_fcmpf(nv, g, 14);   // lanes with nv != g (14 = FCMP_UNE), as a v_cmp into an SGPR pair
                         g = gn;
-                        // value before wake bit: the LDS executes the DS instructions of one wave in issue order,
-                        // so the ds_write above is performed before the ds_or below without waiting for it
-                        // (a workgroup-scope release fence costs an s_waitcnt lgkmcnt(0) = one more LDS round
-                        // trip per sweep); the compiler only has to keep the order
-                        UFM_SWEEP_FENCE();
+                        UFM_SWEEP_FENCE();                               // value before wake bit
                         if ((mask & wake_sel) != 0ull && wbit[j] && lane != 4)
                             __hip_atomic_fetch_or(&s_wake[wword[j]], wbit[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                         ++cnt[j];
