@@ -1,0 +1,43 @@
+"""-m gpu: bench.py's output contract on a small instance of the headline workload (the driver runs the
+full-size one): one JSON line with the metric, the roofline object of the dominant kernel and the CPU
+baseline, and the same line with the collectives switched on (one rank on RCCL)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(*extra):
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29577")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--size", "1024", "--patches", "6", "--steps", "1",
+                          "--warmup", "1", "--cpu-size", "256", *extra], capture_output=True, text=True, timeout=600, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+def test_bench_line_single_gpu():
+    d = _run()
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["unit"] == "cells/s" and d["scaling"] == "weak" and d["dtype"] == "f32"
+    assert d["value"] > 0 and d["vs_baseline"] is None
+    r = d["roofline"]
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12 and r["avg_launch_us"] > 0 and r["timed_launches"] > 0
+    c = d["cpu_baseline"]
+    assert c["kind"] == "port" and c["cores"] == 1 and c["value"] > 0 and "sample" in c
+
+
+def test_bench_line_with_collectives_one_rank():
+    d = _run("--force-dist", "--no-cpu-baseline")        # RCCL: init, broadcast per replan (one ahead), all_reduce, barrier
+    assert d["n_gpus"] == 1 and d["value"] > 0
+    d = _run("--force-dist", "--no-pipeline", "--no-cpu-baseline")
+    assert d["value"] > 0
