@@ -598,3 +598,33 @@ def test_random_small_maps_with_obstacles_and_patches(algo, lvl):
             assert np.array_equal(dev[0], ref[0]) and np.array_equal(dev[1], ref[1]) and dev[2] == ref[2], what
         assert np.array_equal(g.read_map(width, length), cur)
         g.close()
+
+
+@pytest.mark.parametrize("algo,lvl", [("FD", 1), ("SG", 2), ("DFM", 1)])
+def test_patches_on_tile_corners_keep_the_layout_copies_sound(algo, lvl):
+    """The engine keeps per-tile copies of cost bytes (a cell on a tile edge belongs to up to four windows)
+    and of neighbours' border values.  Single-cell and 2x2 patches on and around tile corners, map corners
+    included, must leave every copy equal to its original (ufm_check_layout, asserted inside check_parity)
+    and the field equal to the oracle's."""
+    width, length = 83, 70          # not multiples of the tile edge
+    rng = np.random.default_rng(7)
+    cost = rng.integers(1, 60, (length, width), dtype=np.uint8)
+    o, g = make_pair(ALGOS[algo], lvl, cost, (3.0, 4.0), (float(length - 3), float(width - 4)))
+    assert o.step() == 0 and g.step() == 0
+    check_parity(o, g, "%s plan" % algo)
+    spots = [(0, 0), (15, 15), (16, 16), (15, 16), (31, 32), (32, 31), (47, 48), (63, 64), (length - 1, width - 1),
+             (length - 2, 15), (16, width - 2), (48, 79)]
+    cur = cost.copy()
+    for k, (x, y) in enumerate(spots):
+        h, w = (1, 1) if k % 2 == 0 else (min(2, length - x), min(2, width - y))
+        patch = np.full((h, w), 200 if k % 3 else 2, dtype=np.uint8)
+        cur[x:x + h, y:y + w] = patch
+        for p in (o, g):
+            p.patch_map(patch, x, y)
+            p.set_start(3.0 + (k % 3), 4.0)
+            assert p.step() == 0
+        n, nbad = check_parity(o, g, "%s patch at (%d,%d)" % (algo, x, y), below_start_key=True)
+        if algo != "DFM":
+            assert nbad == 0
+    assert np.array_equal(g.read_map(width, length), cur)
+    g.close()
