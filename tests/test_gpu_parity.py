@@ -145,14 +145,20 @@ def test_focused_and_full_field_agree_below_the_start_key(algo):
 
 
 def test_result_independent_of_scheduler_knobs():
-    """Band width, sweep cap and grid size are scheduling knobs only (full-field mode: bitwise)."""
+    """Band width, sweep cap, grid size, batch submission and hand-out mode are scheduling knobs only
+    (full-field mode: bitwise)."""
     width, length = 224, 160
     cost = ufm_amd.synth.cost_map(4, width, length)
     start, goal = ufm_amd.synth.start_goal(width, length)
     fields = []
-    for scale, cap, grid in [(1.0, 128, 512), (0.25, 128, 512), (1e9, 128, 64), (2.0, 3, 7)]:
+    for scale, cap, grid, extra in [(1.0, 128, 512, {}), (0.25, 128, 512, {}), (1e9, 128, 64, {}), (2.0, 3, 7, {}),
+                                    (1.5, 32, 64, {"pipeline_batches": 0}),            # host waits for every batch of launches
+                                    (1.5, 32, 64, {"delta_scale_long": 3.0, "batch": 2}),   # other band for long queues, short batches
+                                    (1.5, 32, 16, {"dynamic": 0})]:                    # fused triage only
         p = ufm_amd.Planner(ufm_amd.ALGO_SG, 0)
         p.set_param("focused", 0); p.set_param("delta_scale", scale); p.set_param("max_iters", cap); p.set_param("grid", grid)
+        for name, val in extra.items():
+            p.set_param(name, val)
         p.set_occupancy_threshold(1); p.set_map(cost); p.set_start(*start); p.set_goal(*goal)
         assert p.step() == 0
         for k, s, top, left, patch in ufm_amd.synth.replan_script(4, width, length, n_patches=5):
