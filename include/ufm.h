@@ -162,6 +162,7 @@ int ufm_batch_reset(ufm_batch_t *b, int i);
 int ufm_batch_step(ufm_batch_t *b, ufm_stats *stats);
 int ufm_batch_read_field(ufm_batch_t *b, int i, int x0, int y0, int nx, int ny, float *g, float *rhs);
 int ufm_batch_check_layout(ufm_batch_t *b, uint64_t *bad_ring_entries, uint64_t *bad_cost_bytes);
+int ufm_batch_set_param(ufm_batch_t *b, const char *name, double value);   /* as ufm_set_param */
 /* all maps in one launch: path_xy [n_maps][cap_points][2], step_costs [n_maps][cap_costs], info [n_maps] */
 int ufm_batch_extract_path(ufm_batch_t *b, int max_steps, int lookahead, int allow_indirect,
                            float *path_xy, int cap_points, float *step_costs, int cap_costs, ufm_path_info *info);

@@ -8,6 +8,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--size", type=int, default=2048)
 ap.add_argument("--maps", default="1,2,4,8")
 ap.add_argument("--algo", default="DFM")
+ap.add_argument("--param", action="append", default=[], help="name=value for ufm_batch_set_param")
 a = ap.parse_args()
 algo = {"FD": 0, "SG": 1, "DFM": 2}[a.algo]
 size = a.size
@@ -16,6 +17,8 @@ start, goal = ufm_amd.synth.start_goal(size, size)
 for n in [int(v) for v in a.maps.split(",")]:
     b = ufm_amd.BatchPlanner(n, algo, 1 if algo != 1 else 2)
     b.set_occupancy_threshold(1)
+    for kv in a.param:
+        b.set_param(kv.split("=")[0], float(kv.split("=")[1]))
     for i in range(n):
         b.set_map(i, costs[i]); b.set_start(i, *start); b.set_goal(i, *goal)
     best = None

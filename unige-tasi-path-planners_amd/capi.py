@@ -21,7 +21,7 @@ SYMBOLS = [
     "ufm_batch_set_occupancy_threshold", "ufm_batch_set_map", "ufm_batch_patch_map",
     "ufm_batch_set_start", "ufm_batch_set_goal", "ufm_batch_reset", "ufm_batch_step",
     "ufm_batch_read_field", "ufm_extract_path", "ufm_batch_extract_path", "ufm_read_info",
-    "ufm_check_layout", "ufm_batch_check_layout",
+    "ufm_check_layout", "ufm_batch_check_layout", "ufm_batch_set_param",
 ]
 
 
@@ -95,6 +95,7 @@ def load_library():
     L.ufm_read_map.argtypes = [vp, vp]
     L.ufm_check_layout.argtypes = [vp, vp, vp]
     L.ufm_batch_check_layout.argtypes = [vp, vp, vp]
+    L.ufm_batch_set_param.argtypes = [vp, C.c_char_p, C.c_double]
     L.ufm_set_param.argtypes = [vp, C.c_char_p, C.c_double]
     L.ufm_set_profiling.argtypes = [vp, i]
     L.ufm_stream.argtypes = [vp]
@@ -328,6 +329,9 @@ class BatchPlanner:
         g = np.empty((nx, ny), dtype=np.float32)
         _chk(self.L.ufm_batch_read_field(self.h, i, 0, 0, nx, ny, g.ctypes.data, None), "ufm_batch_read_field")
         return g
+
+    def set_param(self, name, value):
+        _chk(self.L.ufm_batch_set_param(self.h, name.encode(), float(value)), "ufm_batch_set_param")
 
     def check_layout(self):
         bad = (C.c_uint64 * 2)()

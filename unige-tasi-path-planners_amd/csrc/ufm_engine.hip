@@ -2435,9 +2435,8 @@ int ufm_read_map(ufm_t *p, uint8_t *host_map) {
     HIPCHK(hipStreamSynchronize(p->e->stream));
     return UFM_OK;
 }
-int ufm_set_param(ufm_t *p, const char *name, double value) {
-    if (!p || !name) return UFM_ERR_INVALID;
-    Engine *e = p->e;
+static int engine_set_param(Engine *e, const char *name, double value) {
+    if (!e || !name) return UFM_ERR_INVALID;
     if (!std::strcmp(name, "delta")) e->delta_abs = (float)value;
     else if (!std::strcmp(name, "delta_scale")) { e->delta_scale = e->delta_scale_long = (float)value; e->delta_abs = -1.0f; }
     else if (!std::strcmp(name, "delta_scale_long")) { e->delta_scale_long = (float)value; e->delta_abs = -1.0f; }
@@ -2459,6 +2458,8 @@ int ufm_set_param(ufm_t *p, const char *name, double value) {
     else return UFM_ERR_INVALID;
     return UFM_OK;
 }
+int ufm_set_param(ufm_t *p, const char *name, double value) { return p ? engine_set_param(p->e, name, value) : UFM_ERR_INVALID; }
+int ufm_batch_set_param(ufm_batch_t *b, const char *name, double value) { return b ? engine_set_param(b->e, name, value) : UFM_ERR_INVALID; }
 int ufm_set_profiling(ufm_t *p, int enable) { if (!p) return UFM_ERR_INVALID; p->e->profiling = enable != 0; return UFM_OK; }
 void *ufm_stream(ufm_t *p) { return p ? (void *)p->e->stream : nullptr; }
 
