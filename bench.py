@@ -4,15 +4,29 @@ plan + 100 replans on a 4096x4096 map, Field D* (level 1), per MI355X.
 
 One "step" = one episode = set the map, plan from scratch, then 100 x (apply a
 31x31 cost patch, move the start, replan).  Inputs (map, patches) are resident
-in HBM before the timed region.  With N > 1 every rank owns an independent map
-instance (weak scaling); the patch stream lives on rank 0 and reaches the other
-ranks by an RCCL broadcast before every replan (the only exchange the path has).
+in HBM before the timed region.  With N > 1 every rank owns independent map
+instances (weak scaling); the patch streams live on rank 0 and reach the other
+ranks by one RCCL broadcast per replan (the only exchange the path has).
+
+  python bench.py                                  config 3 (the headline), one GPU
+  python bench.py --gpus 8                         the same on 8 GPUs: starts 8 ranks itself
+  python bench.py --gpus 8 --algo DFM --size 2048 --batch 8 --seed 1000     config 4: 64 maps, 8 per GPU,
+                                                   every map with a patch stream of its own
+  python bench.py --size 8192 --seed 42 --heuristic                          config 5 (this GPU's replica)
+
+`--gpus N` with N > 1 and no WORLD_SIZE in the environment: this process starts N rank processes (fresh
+interpreters, RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set) before anything touches a GPU, relays rank 0's
+line and exits with the first non-zero exit code.  Under `python -m torch.distributed.run` the ranks exist
+already and each process is one of them.
 
 Prints ONE JSON line on rank 0.
 """
 import argparse
+import importlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -21,135 +35,166 @@ sys.path.insert(0, ROOT)
 
 import numpy as np  # noqa: E402
 
+
 def bytes_per_tile_visit(tile):
     """9 B per element relaxation (4 B G read + 1 B cost + 4 B G write) + the halo"""
     return 9 * tile * tile + (4 * tile + 4) * 4
+
+
 HBM_PEAK_GBS = 8000.0                                         # MI355X_MICROARCH.md: HBM3E peak
+ALGO_LABEL = {"FD": "Field D* level-1", "SG": "Shifted-Grid FM level-2", "DFM": "MS-DFM level-1"}
 
 
-def cpu_baseline(size, seed, n_patches, algo_name="FD", heuristic=False):
-    """The oracle (a C port of the reference's D*-Lite planners; FD-1 for the headline) timed on one
-    host core on a bounded sample of the same workload.  Checker/baseline only."""
+def opt_level(algo_name):
+    return 2 if algo_name == "SG" else 1
+
+
+# ---------------------------------------------------------------------------------------------------------
+# CPU baseline: the oracle (a C port of the reference's D*-Lite planners) on the host cores.  Checker /
+# baseline only.  One map = one process pinned to one core, like the reference driver (main.cpp:36-40);
+# a batch = one such process per map, side by side on as many cores as there are maps (or cores).
+# ---------------------------------------------------------------------------------------------------------
+def cpu_worker(spec):
+    """Runs in a fresh process (`bench.py --cpu-worker JSON`): one map's episode on the oracle, one core."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import oracle_py as orc
     import ufm_amd
     try:
-        os.sched_setaffinity(0, {sorted(os.sched_getaffinity(0))[0]})   # reference pins to one core (main.cpp:36-40)
+        cores = sorted(os.sched_getaffinity(0))
+        os.sched_setaffinity(0, {cores[spec["core"] % len(cores)]})
     except Exception:
         pass
+    size, seed, algo_name = spec["size"], spec["seed"], spec["algo"]
     cost = ufm_amd.synth.cost_map(seed, size, size)
     start, goal = ufm_amd.synth.start_goal(size, size)
     oalgo = {"FD": orc.ALGO_FD, "SG": orc.ALGO_SG, "DFM": orc.ALGO_DFM}[algo_name]
-    p = orc.OraclePlanner(oalgo, 2 if algo_name == "SG" else 1, heuristic)
+    p = orc.OraclePlanner(oalgo, opt_level(algo_name), spec["heuristic"])
     p.reset(); p.set_occupancy_threshold(1)
-    if heuristic:
+    if spec["heuristic"]:
         p.set_heuristic_multiplier(float(cost.min()))
     p.set_map(cost); p.set_start(*start); p.set_goal(*goal)
     exp, ms = 0, 0.0
+    t0 = time.perf_counter()
     assert p.step() == 0
     exp += p.num_expanded; ms += p.u_time + p.p_time
-    for k, s, top, left, patch in ufm_amd.synth.replan_script(seed, size, size, n_patches=n_patches):
+    for k, s, top, left, patch in ufm_amd.synth.replan_script(seed, size, size, n_patches=spec["patches"]):
         p.patch_map(patch, top, left); p.set_start(*s)
         assert p.step() == 0
         exp += p.num_expanded; ms += p.u_time + p.p_time
-    return {"value": exp / (ms * 1e-3), "unit": "cells/s", "cores": 1, "kind": "port",
-            "sample": "%s-%d%s %dx%d seed %d, full plan + %d replans, %d expansions in %.1f s" % (
-                algo_name, 2 if algo_name == "SG" else 1, " heuristic keys" if heuristic else "", size, size, seed, n_patches, exp, ms * 1e-3)}
+    print(json.dumps({"expanded": exp, "ms": ms, "wall_s": time.perf_counter() - t0}))
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--size", type=int, default=4096)
-    ap.add_argument("--patches", type=int, default=100)
-    ap.add_argument("--seed", type=int, default=7, help="seed of the synthetic map and patch script (SURVEY 8d: 7 for the headline, 42 for config 5)")
-    ap.add_argument("--algo", default="FD", choices=["FD", "SG", "DFM"])
-    ap.add_argument("--heuristic", action="store_true",
-                    help="heuristic keys with hm = the map's smallest cost (planners built without -DNO_HEURISTIC; BASELINE config 5 with --size 8192)")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-size", type=int, default=4096, help="map size of the CPU baseline sample (4096 = the identical workload, ~5 s)")
-    ap.add_argument("--no-profile", action="store_true", help="skip per-launch HIP event timing")
-    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
-                    help="collective backend for N > 1 (nccl = RCCL; gloo only to rehearse the control flow, staging through host memory)")
-    ap.add_argument("--no-pipeline", action="store_true",
-                    help="broadcast each patch right before its replan instead of one replan ahead")
-    ap.add_argument("--force-dist", action="store_true",
-                    help="initialise the process group and run the collectives even with one rank (rehearses the RCCL path on a one-GPU box)")
-    args = ap.parse_args()
+def cpu_baseline(size, seed, n_patches, algo_name, heuristic, n_maps):
+    cores_host = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    used = max(1, min(n_maps, cores_host))
+    specs = [{"size": size, "seed": seed + m, "algo": algo_name, "heuristic": heuristic, "patches": n_patches, "core": m} for m in range(n_maps)]
+    results, t0 = [], time.perf_counter()
+    for lo in range(0, n_maps, used):       # waves of `used` processes when there are more maps than cores
+        procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__), "--cpu-worker", json.dumps(sp)],
+                                  stdout=subprocess.PIPE, text=True) for sp in specs[lo:lo + used]]
+        for pr in procs:
+            out, _ = pr.communicate()
+            if pr.returncode != 0:
+                raise RuntimeError("cpu baseline worker failed")
+            results.append(json.loads(out.strip().splitlines()[-1]))
+    wall = time.perf_counter() - t0
+    exp = sum(r["expanded"] for r in results)
+    if n_maps == 1:     # the reference's own accounting: sum of expansions / sum of (u_time + p_time)
+        value, how = exp / (results[0]["ms"] * 1e-3), "%d expansions in %.1f s" % (exp, results[0]["ms"] * 1e-3)
+    else:               # a batch: all maps' expansions over the time the slowest process needed
+        slow = max(r["ms"] for r in results) * 1e-3
+        value, how = exp / slow, "%d expansions, slowest process %.1f s (wall incl. start-up %.1f s)" % (exp, slow, wall)
+    return {"value": value, "unit": "cells/s", "cores": used, "cores_used": used, "cores_host": cores_host, "kind": "port",
+            "sample": "%s-%d%s %dx%d, %s, full plan + %d replans each: %s" % (
+                algo_name, opt_level(algo_name), " heuristic keys" if heuristic else "", size, size,
+                "seed %d" % seed if n_maps == 1 else "%d maps (seeds %d..%d), one pinned process per map on %d of %d host cores" % (
+                    n_maps, seed, seed + n_maps - 1, used, cores_host), n_patches, how)}
 
+
+# ---------------------------------------------------------------------------------------------------------
+# launcher
+# ---------------------------------------------------------------------------------------------------------
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def launch_ranks(n):
+    """Start n rank processes of this script (one per GPU) and relay rank 0's output.  Nothing in this process
+    has touched torch or the GPU."""
+    port = os.environ.get("MASTER_PORT") or str(free_port())
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=port)
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=(r == 0)))
+    rc = 0
+    out0, _ = procs[0].communicate()
+    for r, pr in enumerate(procs):
+        code = pr.wait()
+        if code != 0 and rc == 0:
+            rc = code
+            print("bench.py: rank %d exited with code %d" % (r, code), file=sys.stderr)
+    sys.stdout.write(out0 or "")
+    sys.stdout.flush()
+    return rc
+
+
+# ---------------------------------------------------------------------------------------------------------
+# one rank
+# ---------------------------------------------------------------------------------------------------------
+def run_rank(args):
     import torch
     import ufm_amd
-    BYTES_PER_TILE_VISIT = bytes_per_tile_visit(ufm_amd.load_library().ufm_tile_edge())
+    ep = ufm_amd.episode
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    # one process per GPU; (a gloo rehearsal on a single-GPU box folds the ranks onto the devices there are)
-    dev_index = local_rank % max(1, torch.cuda.device_count())
-    torch.cuda.set_device(dev_index)
+    rehearsal = args.planner_factory is not None          # CPU stand-in planner (tests of the multi-rank control flow)
+    if rehearsal:
+        mod, fn = args.planner_factory.split(":")
+        factory = getattr(importlib.import_module(mod), fn)
+        dev, dev_index = torch.device("cpu"), 0
+        if args.backend == "nccl":
+            raise SystemExit("--planner-factory runs on the CPU: use --backend gloo")
+    else:
+        # one process per GPU; (a gloo rehearsal on a single-GPU box folds the ranks onto the devices there are)
+        dev_index = local_rank % max(1, torch.cuda.device_count())
+        torch.cuda.set_device(dev_index)
+        dev = torch.device("cuda", dev_index)
     if world > 1 or args.force_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if world == 1:
             os.environ.setdefault("MASTER_PORT", "29511"); os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
         if args.backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
+            dist.init_process_group("nccl", device_id=dev)
         else:
             dist.init_process_group("gloo")
     else:
         dist = None
-    dev = torch.device("cuda", dev_index)
 
     size, seed = args.size, args.seed
     algo = {"FD": ufm_amd.ALGO_FD, "SG": ufm_amd.ALGO_SG, "DFM": ufm_amd.ALGO_DFM}[args.algo]
-    # independent map instance per rank; rank 0's instance is the BASELINE seed
-    cost = ufm_amd.synth.cost_map(seed + 1000 * rank, size, size)
+    lvl = opt_level(args.algo)
+    M = args.batch
+    n_local = max(1, M)
     start, goal = ufm_amd.synth.start_goal(size, size)
-    script = list(ufm_amd.synth.replan_script(seed, size, size, n_patches=args.patches))
-    d_cost = torch.from_numpy(cost).to(dev)
-    psz = script[0][4].shape[0] if script else 31
-    if rank == 0 and script:
-        d_patches = torch.from_numpy(np.stack([s[4] for s in script])).to(dev)
-    else:
-        d_patches = torch.empty((max(1, len(script)), psz, psz), dtype=torch.uint8, device=dev)
-    d_recv = [torch.empty((psz, psz), dtype=torch.uint8, device=dev) for _ in range(2)]
+    tile = 16 if rehearsal else ufm_amd.load_library().ufm_tile_edge()
+    BYTES_PER_TILE_VISIT = bytes_per_tile_visit(tile)
 
-    planner = ufm_amd.Planner(algo, 1 if algo != ufm_amd.ALGO_SG else 2, bool(args.heuristic), device=dev_index)
-    if args.heuristic:
-        planner.set_heuristic_multiplier(float(cost.min()))
-    planner.set_occupancy_threshold(1)
-    planner.set_profiling(not args.no_profile)
-    # HIP events on every 16th launch of a plan (~110 timed launches per run): the event packets cost ~4 us each,
-    # with every 4th launch timed the episode was 3 % slower than untimed
-    planner.set_param("profile_stride", 16)
-
-    ep = ufm_amd.episode
-    # The engine's HIP stream becomes torch's current stream: the collective's completion is then a
-    # dependency of the engine's own stream (RCCL chains its internal stream to the current one), with no
-    # further event hop and no host block between the broadcast and the patch kernel.  (Measured with one
-    # rank on RCCL: 38 us per replan with a separate wait_stream() hop, 21 us this way.)
-    try:
-        eng_stream = torch.cuda.ExternalStream(planner.stream_ptr(), device=dev)
-        torch.cuda.set_stream(eng_stream)
-        patch_ready = None
-    except Exception:   # no external-stream support in this torch build: block the host instead
-        patch_ready = lambda: torch.cuda.current_stream().synchronize()
-    stream = ep.PatchStream(d_patches if rank == 0 else None, d_recv, dist=dist, rank=rank, sync=patch_ready,
-                            pipeline=not args.no_pipeline, count=len(script))
-    meta = [(k, s, top, left) for (k, s, top, left, _) in script]
-
-    ptr_cache = {}
-
-    def apply_patch(p, buf, top, left):
-        key = id(buf)
-        ptr = ptr_cache.get(key)
-        if ptr is None:
-            ptr = ptr_cache[key] = buf.data_ptr()      # the per-patch views live as long as the stream
-        p.patch_map_device(ptr, top, left, psz, psz)
+    def on_dev(a):
+        t = torch.from_numpy(np.ascontiguousarray(a))
+        return t if rehearsal else t.to(dev)
 
     def step_stats(p):
+        if rehearsal:
+            return {"cells": p.num_nodes_expanded}
         st = p.stats
         d = {"cells": st.expanded, "visits": st.tile_visits, "launches": st.launches, "kernel_ms": st.kernel_ms, "evals": st.elem_evals,
              "lower_visits": 0, "lower_launches": 0, "lower_kernel_ms": 0.0, "lower_timed": 0}
@@ -160,49 +205,177 @@ def main():
                      lower_kernel_ms=st.kernel_ms - st.raise_kernel_ms, lower_timed=timed)
         return d
 
-    def run_one():
-        return ep.run_episode(
-            planner,
-            set_map=lambda p: p.set_map_device(d_cost.data_ptr(), size, size),
-            start=start, goal=goal, script=meta, stream=stream,
-            apply_patch=apply_patch,
-            read_stats=step_stats)
+    def adopt_stream(ptr):
+        # The engine's HIP stream becomes torch's current stream: the collective's completion is then a
+        # dependency of the engine's own stream (RCCL chains its internal stream to the current one), with no
+        # further event hop and no host block between the broadcast and the patch kernel.  (Measured with one
+        # rank on RCCL: 38 us per replan with a separate wait_stream() hop, 21 us this way.)
+        try:
+            torch.cuda.set_stream(torch.cuda.ExternalStream(ptr, device=dev))
+            return None
+        except Exception:   # no external-stream support in this torch build: block the host instead
+            return lambda: torch.cuda.current_stream().synchronize()
+
+    if M == 0:
+        # ---- one map instance per rank (configs 2, 3, 5); rank 0's instance is the BASELINE seed ----
+        cost = ufm_amd.synth.cost_map(seed + 1000 * rank, size, size)
+        script = list(ufm_amd.synth.replan_script(seed, size, size, n_patches=args.patches))
+        psz = script[0][4].shape[0] if script else 31
+        d_cost = on_dev(cost)
+        if rank == 0 and script:
+            d_patches = on_dev(np.stack([s[4] for s in script]))
+        else:
+            d_patches = torch.empty((max(1, len(script)), psz, psz), dtype=torch.uint8, device=dev)
+        d_recv = [torch.empty((psz, psz), dtype=torch.uint8, device=dev) for _ in range(2)]
+        if rehearsal:
+            planner = factory("single", args.algo, lvl, bool(args.heuristic), 1)
+        else:
+            planner = ufm_amd.Planner(algo, lvl, bool(args.heuristic), device=dev_index)
+        if args.heuristic:
+            planner.set_heuristic_multiplier(float(cost.min()))
+        planner.set_occupancy_threshold(1)
+        patch_ready = None
+        if not rehearsal:
+            planner.set_profiling(not args.no_profile)
+            # HIP events on every 16th launch of a plan (~110 timed launches per run): the event packets cost ~4 us
+            # each, with every 4th launch timed the episode was 3 % slower than untimed
+            planner.set_param("profile_stride", 16)
+            patch_ready = adopt_stream(planner.stream_ptr())
+        stream = ep.PatchStream(d_patches if rank == 0 else None, d_recv, dist=dist, rank=rank, sync=patch_ready,
+                                pipeline=not args.no_pipeline, count=len(script))
+        meta = [(k, s, top, left) for (k, s, top, left, _) in script]
+        ptr_cache = {}
+
+        def apply_patch(p, buf, top, left):
+            if rehearsal:
+                p.patch_map(buf.numpy(), top, left)
+                return
+            key = id(buf)
+            ptr = ptr_cache.get(key)
+            if ptr is None:
+                ptr = ptr_cache[key] = buf.data_ptr()      # the per-patch views live as long as the stream
+            p.patch_map_device(ptr, top, left, psz, psz)
+
+        def set_map(p):
+            if rehearsal:
+                p.set_map(cost)
+            else:
+                p.set_map_device(d_cost.data_ptr(), size, size)
+
+        def run_one():
+            return ep.run_episode(planner, set_map=set_map, start=start, goal=goal, script=meta, stream=stream,
+                                  apply_patch=apply_patch, read_stats=step_stats)
+
+        def self_check():
+            # every rank's raster must now be its own map with all the broadcast patches applied -- a collective
+            # that delivered late or wrong data fails here
+            expect = cost.copy()
+            for (_k, _s, top, left, patch) in script:
+                expect[top:top + patch.shape[0], left:left + patch.shape[1]] = patch
+            return [(0, planner.read_map(size, size), expect)]
+        n_rounds = len(script)
+    else:
+        # ---- M independent maps per rank, every map with its own patch stream (config 4) ----
+        first = rank * M
+        n_global = world * M
+        costs = [ufm_amd.synth.cost_map(seed + first + m, size, size) for m in range(M)]
+        n_rounds = args.patches
+        d_costs = [on_dev(c) for c in costs]
+        starts, rounds, psz = [], None, 31
+        scripts = {}
+        if n_rounds:
+            gen0 = list(ufm_amd.synth.replan_script(seed, size, size, n_patches=n_rounds))
+            starts = [s for (_k, s, _t, _l, _p) in gen0]       # every map's robot advances alike
+            psz = gen0[0][4].shape[0]
+        if rank == 0 and n_rounds:
+            gens = [list(ufm_amd.synth.replan_script(seed + g, size, size, n_patches=n_rounds)) for g in range(n_global)]
+            rounds = on_dev(np.stack([ep.pack_round([(g, gens[g][i][2], gens[g][i][3], gens[g][i][4]) for g in range(n_global)], psz)
+                                      for i in range(n_rounds)]))
+        for m in range(M):      # for the self-check only
+            scripts[m] = list(ufm_amd.synth.replan_script(seed + first + m, size, size, n_patches=n_rounds))
+        rec = (ep.REC_HDR + psz * psz + 15) // 16 * 16
+        d_recv = [torch.empty((n_global, rec), dtype=torch.uint8, device=dev) for _ in range(2)]
+        if rehearsal:
+            planner = factory("batch", args.algo, lvl, bool(args.heuristic), M)
+        else:
+            planner = ufm_amd.BatchPlanner(M, algo, lvl, bool(args.heuristic), device=dev_index)
+        if args.heuristic:
+            planner.set_heuristic_multiplier(float(min(c.min() for c in costs)))
+        planner.set_occupancy_threshold(1)
+        if not rehearsal:
+            planner.set_profiling(not args.no_profile)
+            planner.set_param("profile_stride", 16)
+            adopt_stream(planner.stream_ptr(0))
+        stream = ep.RoundStream(rounds, d_recv, n_rounds, dist=dist, rank=rank, pipeline=not args.no_pipeline)
+
+        def headers_of(buf):
+            # the record headers on the host (the planner surface takes positions as plain ints); for a received
+            # buffer this is also the point where the host knows the broadcast has landed
+            return buf[:, :ep.REC_HDR].cpu().numpy().view(np.int32).reshape(-1, 4)
+
+        def apply_record(b, m, buf, g, top, left, edge):
+            if rehearsal:
+                b.patch_map(m, buf[g, ep.REC_HDR:ep.REC_HDR + edge * edge].numpy().reshape(edge, edge), top, left)
+            else:
+                b.patch_map_device(m, buf.data_ptr() + g * buf.stride(0) + ep.REC_HDR, top, left, edge, edge)
+
+        def set_maps(b):
+            for m in range(M):
+                if rehearsal:
+                    b.set_map(m, costs[m])
+                else:
+                    b.set_map_device(m, d_costs[m].data_ptr(), size, size)
+
+        def run_one():
+            return ep.run_batch_episode(planner, M, first, set_maps, start, goal, starts, stream, headers_of, apply_record, step_stats)
+
+        def self_check():
+            out = []
+            for m in (0, M - 1):
+                expect = costs[m].copy()
+                for (_k, _s, top, left, patch) in scripts[m]:
+                    expect[top:top + patch.shape[0], left:left + patch.shape[1]] = patch
+                out.append((m, planner.read_map(m, size, size), expect))
+            return out
 
     def barrier():
-        torch.cuda.synchronize()
+        if not rehearsal:
+            torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
-        torch.cuda.synchronize()
+        if not rehearsal:
+            torch.cuda.synchronize()
 
     dt, per_step = ep.timed_episodes(run_one, args.steps, args.warmup, barrier)
-    tot = [sum(d[k] for d in per_step) for k in ("cells", "visits", "launches", "kernel_ms", "evals")]
-    low = [sum(d[k] for d in per_step) for k in ("lower_visits", "lower_launches", "lower_kernel_ms", "lower_timed")]
+    keys = ("cells", "visits", "launches", "kernel_ms", "evals")
+    tot = [sum(d.get(k, 0) for d in per_step) for k in keys]
+    low = [sum(d.get(k, 0) for d in per_step) for k in ("lower_visits", "lower_launches", "lower_kernel_ms", "lower_timed")]
 
-    # self-check of the patch path (outside the timed region): every rank's raster must now be its own
-    # map with all the broadcast patches applied -- a collective that delivered late or wrong data fails here
-    expect = cost.copy()
-    for (_k, _s, top, left, patch) in script:
-        expect[top:top + patch.shape[0], left:left + patch.shape[1]] = patch
-    got = planner.read_map(size, size)
-    if not np.array_equal(got, expect):
-        bad = np.argwhere(got != expect)
-        raise RuntimeError("rank %d: raster on the device differs from map + patches in %d cells, first at %r (device %d, expected %d)" % (
-            rank, len(bad), tuple(bad[0]), got[tuple(bad[0])], expect[tuple(bad[0])]))
+    # self-check of the patch path (outside the timed region)
+    for m, got, expect in self_check():
+        if not np.array_equal(got, expect):
+            bad = np.argwhere(got != expect)
+            raise RuntimeError("rank %d map %d: raster on the device differs from map + patches in %d cells, first at %r (device %d, expected %d)" % (
+                rank, m, len(bad), tuple(bad[0]), got[tuple(bad[0])], expect[tuple(bad[0])]))
 
     cells, visits, launches, kms, evals = tot
     if dist is not None:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-        c = torch.tensor([cells, visits, launches, evals], dtype=torch.float64, device=dev)
+        c = torch.tensor([cells, visits, launches, evals, stream.broadcasts], dtype=torch.float64, device=dev)
         dist.all_reduce(c, op=dist.ReduceOp.SUM)
         cells_all = float(c[0].item())
+        bcast_all = int(c[4].item())
     else:
         cells_all = float(cells)
+        bcast_all = 0
 
     if rank == 0:
+        episodes = args.steps + args.warmup
+        maps_desc = "one map instance per GPU" if M == 0 else "%d independent maps per GPU (seeds %d + global map id), every map with a patch stream of its own" % (M, seed)
         out = {
-            "metric": "grid cells updated/sec (full plan + 100 replans), %d^2 map" % size,
+            "metric": "grid cells updated/sec (full plan + %d replans), %d^2 map" % (n_rounds, size),
             "value": cells_all / dt,
             "unit": "cells/s",
             "n_gpus": world,
@@ -215,38 +388,44 @@ def main():
             "dtype": "f32",
             "data": "synthetic",
             "config": {
-                "workload": "%s, %dx%d cost map (seed %d generator, SURVEY 8d), full plan + %d 31x31 patches with moving start, one map instance per GPU" % (
-                    {"FD": "Field D* level-1", "SG": "Shifted-Grid FM level-2", "DFM": "MS-DFM level-1"}[args.algo], size, size, seed, len(script)),
-                "algo": args.algo, "size": size, "patches": len(script), "heuristic_keys": bool(args.heuristic),
+                "workload": "%s, %dx%d cost map (seed %d generator, SURVEY 8d), full plan + %d 31x31 patches with moving start, %s" % (
+                    ALGO_LABEL[args.algo], size, size, seed, n_rounds, maps_desc),
+                "algo": args.algo, "size": size, "patches": n_rounds, "heuristic_keys": bool(args.heuristic),
+                "maps_per_gpu": n_local, "maps_total": n_local * world,
+                # one broadcast per replan (round) per rank, warm-up episodes included; 0 without a process group
+                "broadcasts_per_rank_per_episode": (bcast_all / world / episodes) if (dist is not None and episodes) else 0,
                 "cells_per_step_rank0": cells / max(1, args.steps),
                 "relax_launches_per_step_rank0": launches / max(1, args.steps),
                 "tile_visits_per_step_rank0": visits / max(1, args.steps),
                 "elem_evals_per_step_rank0": evals / max(1, args.steps),
             },
         }
+        if rehearsal:
+            out["rehearsal"] = "CPU stand-in planner %s over %s: control flow only, not a measurement" % (args.planner_factory, args.backend)
         lvis, llaunch, lkms, ltimed = low
-        if lkms > 0 and llaunch > 0 and ltimed > 0:
+        if not rehearsal and lkms > 0 and llaunch > 0 and ltimed > 0:
             # dominant kernel: k_relax<algo, LOWER>.  Algorithmic bytes = tile visits x (9 B per element
             # + halo) per SURVEY.md 8(d); duration = HIP events on the engine's stream around its launches.
             # (the events bracket a sample of the launches -- every 16th of a plan --
             # so that they can stay on inside the timed region: ltimed of the llaunch launches)
             avg_launch_s = lkms * 1e-3 / ltimed
             achieved = (lvis / llaunch) * BYTES_PER_TILE_VISIT / avg_launch_s / 1e9
-            traffic = None
-            tj = os.path.join(ROOT, "profiles", "r1_traffic.json")
-            if os.path.exists(tj) and args.algo == "FD" and size == 4096:
-                traffic = json.load(open(tj)).get("traffic_bytes_per_launch")   # rocprofv3 PMC, same command
+            traffic, traffic_source = None, None
+            tj = os.path.join(ROOT, "profiles", args.traffic_json)
+            if os.path.exists(tj) and args.algo == "FD" and size == 4096 and M == 0 and not args.heuristic:
+                traffic = json.load(open(tj)).get("traffic_bytes_per_launch")
+                traffic_source = "profiles/%s: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, collected separately (not in this run)" % args.traffic_json
             out["roofline"] = {
                 "bound": "hbm", "kernel": "k_relax<%s,LOWER,cursor> (the lowering kernel as launched by the plans)" % args.algo, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
                 "avg_launch_us": 1e6 * avg_launch_s, "timed_launches": ltimed, "launches": llaunch,
                 "algorithmic_bytes_per_launch": lvis * BYTES_PER_TILE_VISIT / llaunch,
                 "tile_visits_per_launch": lvis / llaunch,
                 "kernel_time_share": avg_launch_s * llaunch / dt,
                 "note": "latency-bound (dependent in-LDS sweeps along the wavefront), not bandwidth-bound: see DESIGN.md",
             }
-        if not args.no_cpu_baseline and world == 1:   # the CPU baseline is reported at N = 1 only
-            out["cpu_baseline"] = cpu_baseline(args.cpu_size, seed, args.patches, args.algo, bool(args.heuristic))
+        if not rehearsal and not args.no_cpu_baseline and world == 1:   # the CPU baseline is reported at N = 1 only
+            out["cpu_baseline"] = cpu_baseline(args.cpu_size, seed, n_rounds, args.algo, bool(args.heuristic), n_local)
         print(json.dumps(out))
     stream.close()
     if dist is not None:
@@ -254,5 +433,51 @@ def main():
         dist.destroy_process_group()
 
 
+def main():
+    if len(sys.argv) >= 3 and sys.argv[1] == "--cpu-worker":
+        cpu_worker(json.loads(sys.argv[2]))
+        return 0
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--size", type=int, default=4096)
+    ap.add_argument("--patches", type=int, default=100)
+    ap.add_argument("--seed", type=int, default=None, help="seed of the synthetic map(s) and patch script(s) (SURVEY 8d: 7 for the headline, 1234 "
+                    "config 2, 42 config 5; with --batch: 1000 + global map id)")
+    ap.add_argument("--algo", default="FD", choices=["FD", "SG", "DFM"])
+    ap.add_argument("--batch", type=int, default=0, help="M > 0: M independent maps per rank in one batch handle, every map with its own patch "
+                    "stream (BASELINE config 4: --gpus 8 --algo DFM --size 2048 --batch 8)")
+    ap.add_argument("--heuristic", action="store_true",
+                    help="heuristic keys with hm = the map's smallest cost (planners built without -DNO_HEURISTIC; BASELINE config 5 with --size 8192)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-size", type=int, default=None, help="map size of the CPU baseline sample (default: the identical workload)")
+    ap.add_argument("--no-profile", action="store_true", help="skip per-launch HIP event timing")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="collective backend for N > 1 (nccl = RCCL; gloo only to rehearse the control flow, staging through host memory)")
+    ap.add_argument("--no-pipeline", action="store_true",
+                    help="broadcast each patch right before its replan instead of one replan ahead")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="initialise the process group and run the collectives even with one rank (rehearses the RCCL path on a one-GPU box)")
+    ap.add_argument("--planner-factory", default=None, metavar="MODULE:FUNCTION",
+                    help="test hook: run the episode on a CPU stand-in planner made by MODULE.FUNCTION(kind, algo, lvl, heuristic, n_maps) "
+                         "(control flow of the launcher / collectives without a GPU; the line is marked as a rehearsal)")
+    ap.add_argument("--traffic-json", default="r2_traffic.json", help="file under profiles/ holding the separately collected PMC traffic of the headline run")
+    args = ap.parse_args()
+    if args.seed is None:
+        args.seed = 1000 if args.batch > 0 else 7
+    if args.cpu_size is None:
+        args.cpu_size = args.size
+    if args.gpus < 1 or args.batch < 0:
+        raise SystemExit("--gpus >= 1, --batch >= 0")
+    env_world = os.environ.get("WORLD_SIZE")
+    if args.gpus > 1 and env_world is None:
+        return launch_ranks(args.gpus)                 # nothing above has imported torch or touched a GPU
+    if env_world is not None and int(env_world) != args.gpus and int(env_world) > 1:
+        print("bench.py: --gpus %d but WORLD_SIZE=%s; the process group decides" % (args.gpus, env_world), file=sys.stderr)
+    run_rank(args)
+    return 0
+
+
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

@@ -59,6 +59,9 @@ typedef struct ufm_stats {
     uint32_t queued_raise;     /*   the counterpart of the reference's priority_queue.size() */
     uint32_t timed_launches;   /* profiling: launches covered by kernel_ms (a sample: every 4th launch of a plan, */
     uint32_t timed_raise_launches; /*   every launch of a replan); of which in the invalidation phase (raise_kernel_ms) */
+    uint32_t graphs_instantiated;  /* cumulative: replan submissions captured and instantiated as hipGraphs by this handle (a
+                                    * new heuristic multiplier / threshold must not add one: they travel through memory) */
+    uint32_t reserved0;
 } ufm_stats;
 
 /* ---- lifetime: `PlannerT<OPT_LVL> planner{}` (e.g. Tests/Planners/FDSTAR/main.cpp:77) ---- */
@@ -146,23 +149,36 @@ void *ufm_stream(ufm_t *p);                    /* hipStream_t the kernels run on
 const char *ufm_version(void);
 int ufm_tile_edge(void);                       /* elements per tile side (for the algorithmic-bytes accounting) */
 
-/* ---- batch of independent map instances on one device (BASELINE config 4).
- * Every map of the batch has the same size / algo; a batch step advances all
- * maps in one set of launches (tiles of all maps share the active lists). ---- */
+/* ---- batch of independent map instances (BASELINE config 4): the reference's counterpart is a set of
+ * independent planner objects (Tests/Planners/DFM/main.cpp:77-88).  Every map of the batch has the same size /
+ * algo; a batch step advances all maps of a device in one set of launches (their tiles share the work queues).
+ * ufm_batch_create puts all maps on one device; ufm_batch_create_sharded spreads them over `devices` in
+ * contiguous blocks (map i -> devices[i / ceil(n_maps / n_devices)]) for a single-process caller: one engine
+ * per device, ufm_batch_step advances them side by side (one host thread per device) and sums the statistics.
+ * (bench.py shards by process instead: one rank per GPU, each with a one-device batch.)
+ * The *_device variants take HBM pointers on the map's device, e.g. a buffer an RCCL broadcast just filled. ---- */
 typedef struct ufm_batch ufm_batch_t;
 int ufm_batch_create(ufm_batch_t **out, int n_maps, int algo, int opt_lvl, int use_heuristic, int device_id);
+int ufm_batch_create_sharded(ufm_batch_t **out, int n_maps, int algo, int opt_lvl, int use_heuristic, const int *devices, int n_devices);
 int ufm_batch_destroy(ufm_batch_t *b);
 int ufm_batch_size(const ufm_batch_t *b);
+int ufm_batch_shards(const ufm_batch_t *b);     /* engines (devices) the maps are spread over */
 int ufm_batch_set_occupancy_threshold(ufm_batch_t *b, float thr);
+int ufm_batch_set_heuristic_multiplier(ufm_batch_t *b, float mult);
 int ufm_batch_set_map(ufm_batch_t *b, int i, const uint8_t *host_map, int width, int length);
+int ufm_batch_set_map_device(ufm_batch_t *b, int i, const uint8_t *dev_map, int width, int length);
 int ufm_batch_patch_map(ufm_batch_t *b, int i, const uint8_t *host_patch, int x, int y, int w, int h);
+int ufm_batch_patch_map_device(ufm_batch_t *b, int i, const uint8_t *dev_patch, int x, int y, int w, int h);
 int ufm_batch_set_start(ufm_batch_t *b, int i, float x, float y);
 int ufm_batch_set_goal(ufm_batch_t *b, int i, float x, float y);
 int ufm_batch_reset(ufm_batch_t *b, int i);
 int ufm_batch_step(ufm_batch_t *b, ufm_stats *stats);
 int ufm_batch_read_field(ufm_batch_t *b, int i, int x0, int y0, int nx, int ny, float *g, float *rhs);
+int ufm_batch_read_map(ufm_batch_t *b, int i, uint8_t *host_map);
 int ufm_batch_check_layout(ufm_batch_t *b, uint64_t *bad_ring_entries, uint64_t *bad_cost_bytes);
 int ufm_batch_set_param(ufm_batch_t *b, const char *name, double value);   /* as ufm_set_param */
+int ufm_batch_set_profiling(ufm_batch_t *b, int enable);
+void *ufm_batch_stream(ufm_batch_t *b, int shard);                         /* hipStream_t of shard's engine */
 /* all maps in one launch: path_xy [n_maps][cap_points][2], step_costs [n_maps][cap_costs], info [n_maps] */
 int ufm_batch_extract_path(ufm_batch_t *b, int max_steps, int lookahead, int allow_indirect,
                            float *path_xy, int cap_points, float *step_costs, int cap_costs, ufm_path_info *info);

@@ -6,6 +6,23 @@ import ufm_amd
 
 ALGOS = {"FD": 0, "SG": 1, "DFM": 2}
 
+# Acceptance bounds on the reference's consistent set, each defined HERE and nowhere else.
+# FD / SG: SURVEY.md 8(d)'s max(1e-6*G, 2 ulp) -- and every FD / SG test asserts bit equality on top of it.
+FIELD_RTOL = 1e-6
+# MS-DFM: 2e-6*G, derived once from the reference algorithm's own spread (reproducible with
+# tools/dfm_fixed_points.py): the float fixed point of DFM's update operator is not unique, and WHICH one an
+# evaluation order lands on is already a last-bits matter between two sequential orders of the reference's own
+# level-1 operator -- the priority-queue order (the oracle) against raster Gauss-Seidel sweeps of the same
+# candidates differ by up to 9 ulp = 1.02e-6 on the 2048^2 maps of BASELINE config 4 (seed 1003); the reference's
+# level-0 planner does not terminate at all on one of them (seed 1000: 1e9 expansions, oracle code -75).  So
+# 1e-6 cannot be promised by anything that does not replay the queue's pop order; the bound is twice the
+# measured spread.  Measured engine-vs-oracle on those eight maps: 4-8 ulp, <= 7.5e-7.
+DFM_RTOL = 2e-6
+
+
+def rtol_for(algo):
+    return DFM_RTOL if algo in (2, "DFM") else FIELD_RTOL
+
 
 def make_pair(algo, opt_lvl, cost, start, goal, thr=1.0, heuristic=False, hm=1.0):
     """Configure an oracle planner and a HIP planner the way the reference's
@@ -32,10 +49,8 @@ def ulp_diff(a, b):
 def check_parity(o, g, what="", below_start_key=False):
     """Compare the HIP field with the oracle on the set of elements whose value
     the reference guarantees final (consistent and not beyond the queue top).
-    Target: bit-equal (FD / SG are asserted bit-equal by the callers).  Acceptance bound
-    (SURVEY.md 8d): |dG| <= max(1e-6*G, 2 ulp); for DFM 2e-6*G: the float fixed point of its upwind
-    quadratic is not unique and the engine cuts ulp-level creep short --
-    measured worst case 13 ulp = 1.2e-6 on 2048^2."""
+    Target: bit-equal (FD / SG are asserted bit-equal by the callers).  Acceptance bound: FIELD_RTOL /
+    DFM_RTOL above, or 2 ulp."""
     og, orhs = o.g(), o.rhs()
     mask = o.trusted_mask(below_start_key=below_start_key)
     gg, grhs = g.read_field()
@@ -49,7 +64,7 @@ def check_parity(o, g, what="", below_start_key=False):
     if nbad:
         ud = ulp_diff(a, b)
         rel = np.abs(a.astype(np.float64) - b) / np.maximum(b, 1e-30)
-        rtol = 2e-6 if o.algo == orc.ALGO_DFM else 1e-6
+        rtol = rtol_for(o.algo)
         assert (ud <= 2).all() or (rel <= rtol).all(), "%s: max ulp %d, max rel %.3g over %d/%d differing" % (
             what, int(ud.max()), float(rel.max()), nbad, n)
     # RHS view: equals G at the fixed point; must agree with the oracle's RHS wherever that is final

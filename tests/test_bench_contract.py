@@ -14,8 +14,11 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def _run(*extra):
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29577")
-    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--size", "1024", "--patches", "6", "--steps", "1",
-                          "--warmup", "1", "--cpu-size", "256", *extra], capture_output=True, text=True, timeout=600, env=env)
+    base = ["--size", "1024", "--patches", "6", "--steps", "1", "--warmup", "1", "--cpu-size", "256"]
+    for i in range(0, len(extra), 1):       # an explicit option overrides the default of the same name
+        if extra[i] in base:
+            j = base.index(extra[i]); del base[j:j + 2]
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *base, *extra], capture_output=True, text=True, timeout=600, env=env)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, out.stdout[-2000:]
@@ -32,8 +35,9 @@ def test_bench_line_single_gpu():
     r = d["roofline"]
     assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12 and r["avg_launch_us"] > 0 and r["timed_launches"] > 0
+    assert "traffic_source" in r                      # the PMC traffic is a separately collected number and says so
     c = d["cpu_baseline"]
-    assert c["kind"] == "port" and c["cores"] == 1 and c["value"] > 0 and "sample" in c
+    assert c["kind"] == "port" and c["cores"] == 1 and c["cores_used"] == 1 and c["cores_host"] >= 1 and c["value"] > 0 and "sample" in c
 
 
 def test_bench_line_with_collectives_one_rank():
@@ -41,3 +45,26 @@ def test_bench_line_with_collectives_one_rank():
     assert d["n_gpus"] == 1 and d["value"] > 0
     d = _run("--force-dist", "--no-pipeline", "--no-cpu-baseline")
     assert d["value"] > 0
+
+
+def test_bench_self_launcher_two_ranks_on_one_gpu():
+    """`--gpus 2` without a launcher around it: bench.py starts both ranks itself; here they share the one GPU
+    of the box and talk over gloo (RCCL needs a device per rank), the planner is the HIP engine."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--size", "1024", "--patches", "6",
+                          "--steps", "1", "--warmup", "1"], capture_output=True, text=True, timeout=600, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["value"] > 0 and "cpu_baseline" not in d
+    assert d["config"]["broadcasts_per_rank_per_episode"] == 6 and d["config"]["maps_total"] == 2
+
+
+def test_bench_batch_config4_shape_small():
+    """config 4's shape on one GPU at a small size: --batch maps in one handle, a patch stream per map, the
+    process-parallel CPU leg with the host's core count in the line"""
+    d = _run("--algo", "DFM", "--batch", "3", "--size", "512", "--cpu-size", "512", "--patches", "4")
+    assert d["config"]["maps_per_gpu"] == 3 and d["value"] > 0 and d["roofline"]["frac"] > 0
+    c = d["cpu_baseline"]
+    assert c["cores_used"] == min(3, c["cores_host"]) and c["value"] > 0

@@ -4,7 +4,7 @@ import pytest
 
 import ufm_amd
 import oracle_py as orc
-from helpers import ALGOS, check_parity, make_pair
+from helpers import ALGOS, DFM_RTOL, check_parity, make_pair
 
 pytestmark = pytest.mark.gpu
 
@@ -58,8 +58,7 @@ def test_replans_synthetic(algo, lvl):
         total_bad += nbad
     # FD / SG: bit-equal.  DFM: the upwind quadratic is not monotone at the ulp level, its
     # float fixed point is not unique (the oracle's own DFM-0 and DFM-1 differ in the last
-    # bits on this map, see tests/test_oracle.py), so DFM is held to the stated tolerance
-    # max(1e-6*G, 2 ulp) that check_parity enforces.
+    # bits on this map, see tests/test_oracle.py), so DFM is held to helpers.DFM_RTOL, which check_parity enforces.
     if algo != "DFM":
         assert total_bad == 0
     # the device raster followed the patches
@@ -136,7 +135,7 @@ def test_focused_and_full_field_agree_below_the_start_key(algo):
         m = gu < key
         assert m.sum() > 100
         if algo == "DFM":   # tolerance: the float fixed point of the DFM quadratic is not unique
-            assert np.all(np.abs(gf[m].astype(np.float64) - gu[m]) <= 1e-6 * gu[m])
+            assert np.all(np.abs(gf[m].astype(np.float64) - gu[m]) <= DFM_RTOL * gu[m])
         else:
             assert np.array_equal(gf[m], gu[m]), "replan %d: %d differ" % (k, int((gf[m] != gu[m]).sum()))
     assert work[0] < work[1]          # focusing must save work
@@ -231,7 +230,7 @@ def test_batch_of_independent_maps():
         m = o.trusted_mask(below_start_key=True)   # what a planner honouring end_condition must have finalised
         a, ref = b.read_field(i)[m], o.g()[m]
         assert m.sum() > 10000
-        assert np.all(np.abs(a.astype(np.float64) - ref) <= 2e-6 * ref)
+        assert np.all(np.abs(a.astype(np.float64) - ref) <= DFM_RTOL * ref)
     # patch two of the maps, leave the others alone
     for i in (1, 3):
         patch = np.full((9, 9), 3 + i, dtype=np.uint8)
@@ -243,7 +242,7 @@ def test_batch_of_independent_maps():
         m = o.trusted_mask(below_start_key=True)
         a, ref = b.read_field(i)[m], o.g()[m]
         err = np.abs(a.astype(np.float64) - ref)
-        assert np.all(err <= 2e-6 * ref), (i, float(err.max()), int(m.sum()))
+        assert np.all(err <= DFM_RTOL * ref), (i, float(err.max()), int(m.sum()))
     assert b.check_layout() == (0, 0)
     b.close()
 
@@ -284,11 +283,13 @@ def test_heuristic_keys(algo, lvl):
     g.close()
 
 
-@pytest.mark.parametrize("algo,size", [("FD", 1024), ("SG", 1024), ("DFM", 1024), ("DFM", 2048)])
-def test_first_plan_large(algo, size):
-    """Larger maps (the oracle still finishes in seconds): FD / SG bit-equal; DFM within 1e-6 --
-    including the 2048^2 map on which the DFM quadratic's ulp-level creep used to take 100 k launches."""
-    cost = ufm_amd.synth.cost_map(1000, size, size)
+@pytest.mark.parametrize("algo,size,seed", [("FD", 1024, 1000), ("SG", 1024, 1000), ("DFM", 1024, 1000), ("DFM", 2048, 1000),
+                                            ("SG", 2048, 1234)])
+def test_first_plan_large(algo, size, seed):
+    """Larger maps (the oracle still finishes in seconds): FD / SG bit-equal (SG at 2048^2 with seed 1234 is
+    BASELINE config 2); DFM within helpers.DFM_RTOL -- including the 2048^2 map on which the level-0 form of the
+    DFM operator never settles (the reference's own DFMPlanner<0> does not terminate there either)."""
+    cost = ufm_amd.synth.cost_map(seed, size, size)
     start, goal = ufm_amd.synth.start_goal(size, size)
     o, g = make_pair(ALGOS[algo], 1 if algo != "SG" else 2, cost, start, goal)
     assert o.step() == 0 and g.step() == 0
@@ -390,7 +391,7 @@ def test_replan_submission_variants_agree(algo, lvl):
                 r0 = results[0][0]
                 fin = np.isfinite(r0)
                 assert np.array_equal(fin, np.isfinite(g))
-                assert np.all(np.abs(g[fin].astype(np.float64) - r0[fin]) <= 4e-6 * r0[fin] + 1e-30)
+                assert np.all(np.abs(g[fin].astype(np.float64) - r0[fin]) <= DFM_RTOL * r0[fin] + 1e-30)
     # focused mode (the last loop): against the oracle, below the start's key
     o = __import__("oracle_py").OraclePlanner(ALGOS[algo], lvl, False)
     o.reset(); o.set_occupancy_threshold(1); o.set_map(cost); o.set_start(*start); o.set_goal(*goal)
@@ -410,16 +411,17 @@ def test_replan_submission_variants_agree(algo, lvl):
     for g, log, m in results:
         a, b = g[mask], og[mask]
         if algo == "DFM":
-            assert np.all(np.abs(a.astype(np.float64) - b) <= 2e-6 * b + 1e-30)
+            assert np.all(np.abs(a.astype(np.float64) - b) <= DFM_RTOL * b + 1e-30)
         else:
             assert np.array_equal(a, b)
 
 
 def test_headline_size_4096_against_oracle_and_properties():
-    """BASELINE.json's headline configuration (Field D* level 1, 4096x4096): the full plan and a few
-    replans are compared with the oracle bit for bit on the set a planner honouring end_condition
-    must have finalised, plus size-independent properties (idempotence, goal value, a second engine
-    in full-field mode agrees below the start's key)."""
+    """BASELINE.json's headline configuration (Field D* level 1, 4096x4096, seed 7): the full plan and ALL 100
+    replans of the episode bench.py times are compared with the oracle bit for bit on the set a planner
+    honouring end_condition must have finalised (after the plan, after each of the first 4 replans, then after
+    every 8th and after the last one; num_nodes_updated after every one), plus size-independent properties
+    (idempotence, goal value, a second engine in full-field mode agrees below the start's key)."""
     size, seed = 4096, 7
     cost = ufm_amd.synth.cost_map(seed, size, size)
     start, goal = ufm_amd.synth.start_goal(size, size)
@@ -431,17 +433,21 @@ def test_headline_size_4096_against_oracle_and_properties():
     n, nbad = check_parity(o, g, "FD-1 4096 plan", below_start_key=True)
     assert n > 16_000_000 and nbad == 0
     assert g.g()[int(goal[0]), int(goal[1])] == 0.0
-    for k, s, top, left, patch in ufm_amd.synth.replan_script(seed, size, size, n_patches=4):
-        for p in (o, g, u):
+    script = list(ufm_amd.synth.replan_script(seed, size, size, n_patches=100))
+    for i, (k, s, top, left, patch) in enumerate(script):
+        for p in (o, g) + ((u,) if i < 4 else ()):
             p.patch_map(patch, top, left)
             p.set_start(*s)
             assert p.step() == 0
-        n, nbad = check_parity(o, g, "FD-1 4096 replan %d" % k, below_start_key=True)
-        assert nbad == 0
-        gf, gu = g.g(), u.g()
-        key = max(gu[int(s[0]) + a, int(s[1]) + b] for a in (0, 1) for b in (0, 1))
-        m = gu < key
-        assert np.array_equal(gf[m], gu[m])
+        assert g.num_nodes_updated == o.num_updated, (k, g.num_nodes_updated, o.num_updated)
+        if i < 4 or i % 8 == 7 or i == len(script) - 1:
+            n, nbad = check_parity(o, g, "FD-1 4096 replan %d" % k, below_start_key=True)
+            assert nbad == 0
+        if i < 4:
+            gf, gu = g.g(), u.g()
+            key = max(gu[int(s[0]) + a, int(s[1]) + b] for a in (0, 1) for b in (0, 1))
+            m = gu < key
+            assert np.array_equal(gf[m], gu[m])
     # idempotence: nothing pending, nothing changes
     before = g.g()
     g.set_start(*s)
@@ -497,9 +503,11 @@ def test_config5_8192_heuristic_keys_moving_start_properties():
 
 
 def test_config4_batch_of_8_maps_2048_dfm():
-    """BASELINE.json config 4, one GPU's share: 8 independent 2048x2048 MS-DFM maps planned in one
-    batch.  Map 5 equals a planner of its own within DFM's tolerance, every map reaches its start,
-    and one launch extracts all eight paths."""
+    """BASELINE.json config 4, one GPU's share: 8 independent 2048x2048 MS-DFM maps (seeds 1000..1007, SURVEY
+    8d) planned in one batch.  Two of the maps are compared with the oracle on the set it guarantees final and a
+    planner honouring end_condition must have finalised (helpers.DFM_RTOL) -- among them seed 1006, on which
+    block Gauss-Seidel between tiles used to cycle --, every map reaches its start, one launch extracts all eight
+    paths, and a replan round with a patch on every map is checked the same way."""
     n, size = 8, 2048
     b = ufm_amd.BatchPlanner(n, ufm_amd.ALGO_DFM, 1)
     b.set_occupancy_threshold(1.0)
@@ -510,19 +518,36 @@ def test_config4_batch_of_8_maps_2048_dfm():
         costs.append(c)
         b.set_map(m, c); b.set_start(m, *start); b.set_goal(m, *goal)
     assert b.step() == 0
-    p = ufm_amd.Planner(ufm_amd.ALGO_DFM, 1)
-    p.set_occupancy_threshold(1.0); p.set_map(costs[5]); p.set_start(*start); p.set_goal(*goal)
-    assert p.step() == 0
-    gb, gp = b.read_field(5), p.g()
-    key = gp[int(start[0]), int(start[1])]
-    m = gp < key
-    assert int(m.sum()) > 3_000_000
-    assert np.all(np.abs(gb[m].astype(np.float64) - gp[m]) <= 4e-6 * gp[m] + 1e-30)
+    oracles = {}
+    for m in (3, 6):
+        o = orc.OraclePlanner(orc.ALGO_DFM, 1, False)
+        o.reset(); o.set_occupancy_threshold(1.0); o.set_map(costs[m]); o.set_start(*start); o.set_goal(*goal)
+        assert o.step() == 0
+        oracles[m] = o
+
+    def against_oracle(what):
+        for m, o in oracles.items():
+            mask = o.trusted_mask(below_start_key=True)
+            assert int(mask.sum()) > 3_000_000
+            a, ref = b.read_field(m)[mask], o.g()[mask]
+            err = np.abs(a.astype(np.float64) - ref)
+            assert np.all(err <= DFM_RTOL * ref), "%s map %d: max rel %.3g" % (what, m, float((err / ref.clip(1)).max()))
+    against_oracle("plan")
     for k in range(n):
         assert np.isfinite(b.read_field(k)[int(start[0]), int(start[1])])
     paths = b.extract_paths(max_steps=20)
     assert len(paths) == n and all(len(pt[0]) >= 2 and pt[2] > 0 for pt in paths)
-    b.close(); p.close()
+    # one replan round: every map gets its own 31x31 patch (map m: step m of its own script)
+    for m in range(n):
+        k, s, top, left, patch = list(ufm_amd.synth.replan_script(1000 + m, size, size, n_patches=m + 1))[m]
+        b.patch_map(m, patch, top, left); b.set_start(m, *s)
+        if m in oracles:
+            oracles[m].patch_map(patch, top, left); oracles[m].set_start(*s)
+            assert oracles[m].step() == 0
+    assert b.step() == 0
+    against_oracle("replan")
+    assert b.check_layout() == (0, 0)
+    b.close()
 
 
 @pytest.mark.parametrize("algo,lvl", [("FD", 1), ("SG", 1), ("SG", 2), ("DFM", 1)])
@@ -634,3 +659,93 @@ def test_patches_on_tile_corners_keep_the_layout_copies_sound(algo, lvl):
             assert nbad == 0
     assert np.array_equal(g.read_map(width, length), cur)
     g.close()
+
+
+def test_heuristic_multiplier_per_move_does_not_re_instantiate_graphs():
+    """The reference harness sends a new min_cost with every move (Tests/Planners/DFM/main.cpp:111-112 ->
+    set_heuristic_multiplier).  The multiplier (like the occupancy threshold) reaches the kernels through device
+    memory, not through the captured graphs' frozen arguments: a replan with a new multiplier replays an existing
+    graph.  Fields are checked against the oracle, which gets the same multipliers."""
+    width = length = 224
+    seed = 31
+    cost = ufm_amd.synth.cost_map(seed, width, length)
+    start, goal = (60.0, 70.0), (float(length - 8), float(width - 8))
+    o, g = make_pair(ALGOS["FD"], 1, cost, start, goal, heuristic=True, hm=1.0)
+    assert o.step() == 0 and g.step() == 0
+    counts = []
+    sx, sy = start
+    for k in range(1, 25):
+        top, left = int(sx) - 15 + 3 * k, int(sy) - 15 + 2 * k
+        patch = (1 + (ufm_amd.synth.h64(seed ^ k, *np.meshgrid(np.arange(top, top + 31), np.arange(left, left + 31), indexing="ij")) % np.uint64(200))).astype(np.uint8)
+        hm = 1.0 - 0.02 * (k % 7)            # a different multiplier every move
+        for p in (o, g):
+            p.patch_map(patch, top, left)
+            p.set_heuristic_multiplier(hm)
+            p.set_start(sx + 3 * k, sy + 2 * k)
+            assert p.step() == 0
+        n, nbad = check_parity(o, g, "hm %.2f replan %d" % (hm, k), below_start_key=True)
+        assert nbad == 0
+        counts.append(g.stats.graphs_instantiated)
+    # graphs are keyed by the launch counts of a submission (what recent replans needed) and by nothing else: far
+    # fewer graphs than replans, although every one of the 24 replans came with a new multiplier
+    assert counts[-1] <= 10, counts
+    g.close()
+
+
+def test_absurd_map_size_fails_cleanly_and_the_handle_survives():
+    """hipMalloc failure half way through alloc(): a negative code, nothing aborts, nothing leaks into the next
+    set_map (which works), destroy is clean."""
+    g = ufm_amd.Planner(ufm_amd.ALGO_FD, 1)
+    L = g.L
+    dummy = np.zeros(16, np.uint8)
+    rc = L.ufm_set_map(g.h, dummy.ctypes.data, 400000, 400000)      # 160 G cells: 640 GB for G alone
+    assert rc < 0 and rc != ufm_amd.LOOP_FAILURE_NO_GRAPH
+    assert g.step() == ufm_amd.LOOP_FAILURE_NO_GRAPH               # still no map
+    cost = ufm_amd.synth.cost_map(3, 96, 96)
+    g.set_occupancy_threshold(1); g.set_map(cost); g.set_start(8.0, 8.0); g.set_goal(88.0, 88.0)
+    assert g.step() == 0 and np.isfinite(g.g()[8, 8])
+    g.close()
+
+
+def test_batch_device_inputs_and_sharded_handle():
+    """ufm_batch_set_map_device / ufm_batch_patch_map_device (HBM pointers, e.g. a buffer an RCCL broadcast
+    filled) and ufm_batch_create_sharded (here: two engines on the one device of the box, devices = [0, 0]; on a
+    node each shard gets its own GPU and ufm_batch_step advances them side by side) give the fields of a
+    one-engine batch fed from host memory, bit for bit (FD, full-field mode)."""
+    import torch
+    n, size = 4, 160
+    costs = [ufm_amd.synth.cost_map(50 + i, size, size) for i in range(n)]
+    start, goal = ufm_amd.synth.start_goal(size, size)
+    scripts = [list(ufm_amd.synth.replan_script(50 + i, size, size, n_patches=3)) for i in range(n)]
+    a = ufm_amd.BatchPlanner(n, ufm_amd.ALGO_FD, 1)
+    b = ufm_amd.BatchPlanner(n, ufm_amd.ALGO_FD, 1, devices=[0, 0])
+    assert b.shards() == 2 and a.shards() == 1
+    d_costs = [torch.from_numpy(c).cuda() for c in costs]
+    for p in (a, b):
+        p.set_param("focused", 0); p.set_occupancy_threshold(1)
+    for i in range(n):
+        a.set_map(i, costs[i]); b.set_map_device(i, d_costs[i].data_ptr(), size, size)
+        for p in (a, b):
+            p.set_start(i, *start); p.set_goal(i, *goal)
+    torch.cuda.synchronize()
+    assert a.step() == 0 and b.step() == 0
+    assert b.stats.expanded == a.stats.expanded
+    for r in range(3):
+        keep = []
+        for i in range(n):
+            k, s, top, left, patch = scripts[i][r]
+            dp = torch.from_numpy(patch.copy()).cuda(); keep.append(dp)
+            torch.cuda.synchronize()
+            a.patch_map(i, patch, top, left); b.patch_map_device(i, dp.data_ptr(), top, left, 31, 31)
+            for p in (a, b):
+                p.set_start(i, *s)
+        assert a.step() == 0 and b.step() == 0
+        assert b.stats.updated == a.stats.updated
+        for i in range(n):
+            assert np.array_equal(a.read_field(i), b.read_field(i)), (r, i)
+            assert np.array_equal(a.read_map(i, size, size), b.read_map(i, size, size))
+    assert b.check_layout() == (0, 0)
+    pa, pb = a.extract_paths(max_steps=10), b.extract_paths(max_steps=10)
+    for x, y in zip(pa, pb):
+        assert np.array_equal(x[0], y[0]) and x[2] == y[2]
+    a.close(); b.close()

@@ -130,3 +130,63 @@ def test_heuristic_keys_same_field_where_final():
     mm = m & (f < k1)
     assert mm.sum() > 50
     assert np.array_equal(ga[mm], gb[mm])
+
+
+def _dfm_operators(G, cost, goal):
+    """numpy float32 restatement of DFM's two update operators on a whole field: F0 = min_rhs<0>
+    (DynamicFastMarching_impl.h:157-210), F1 = the smallest of the eight candidates of
+    min_rhs_decreased_neighbor (:270-313) -- what DFMPlanner<1>::plan keeps in RHS (:79-86)."""
+    f32 = np.float32
+    S2 = f32(1.41421356237309504880168872420969807856967187537694)
+    nx, ny = G.shape
+    tau = cost.astype(f32)
+    tau[cost >= 255] = np.inf
+
+    def Q(a, b, th):      # compute_optimal_cost, :322-342
+        ga, gb = np.minimum(a, b), np.maximum(a, b)
+        with np.errstate(invalid="ignore"):
+            d = gb - ga
+            s = ((ga + gb) + np.sqrt(f32(2.0) * (th * th) - d * d)) * f32(0.5)
+            r = np.where(th > d, s, ga + th)
+        return np.where(np.isnan(r), np.inf, r).astype(f32)
+
+    P = np.pad(G, 1, constant_values=np.inf)
+    sh = lambda dx, dy: P[1 + dx:1 + dx + nx, 1 + dy:1 + dy + ny]
+    T, B, L, R = sh(-1, 0), sh(1, 0), sh(0, -1), sh(0, 1)
+    TL, BR, BL, TR = sh(-1, -1), sh(1, 1), sh(1, -1), sh(-1, 1)
+    th2 = (tau * S2).astype(f32)
+    lr, tb, d1, d2 = np.minimum(L, R), np.minimum(T, B), np.minimum(TL, BR), np.minimum(BL, TR)
+    o, d = Q(tb, lr, tau), Q(d1, d2, th2)
+    F0 = np.where(d < o, d, o)
+    F1 = Q(T, lr, tau)
+    for c in (Q(B, lr, tau), Q(L, tb, tau), Q(R, tb, tau), Q(TR, d1, th2), Q(BL, d1, th2), Q(TL, d2, th2), Q(BR, d2, th2)):
+        F1 = np.minimum(F1, c)
+    for F in (F0, F1):
+        F[np.isinf(tau)] = np.inf
+        F[goal] = 0
+    return F0, F1
+
+
+def test_dfm_level1_field_is_the_fixed_point_of_the_candidate_operator():
+    """Which operator does DFMPlanner<1> compute?  On its consistent set the oracle's level-1 field satisfies
+    G = F1(G) exactly -- F1 = the smallest of the eight per-neighbour candidates -- and NOT G = F0(G) (the
+    level-0 min_rhs): the float quadratic is not monotone, so 'best cell of a pair first' and 'smallest
+    candidate' part in the last bit where two fronts meet.  The engine relaxes F1 for level 1 for this reason
+    (ufm_engine.hip, ALGO_DFM1)."""
+    size = 1024
+    cost = ufm_amd.synth.cost_map(1000, size, size)
+    start, goal = ufm_amd.synth.start_goal(size, size)
+    o = orc.OraclePlanner(orc.ALGO_DFM, 1, False)
+    o.reset(); o.set_occupancy_threshold(1); o.set_map(cost); o.set_start(*start); o.set_goal(*goal)
+    assert o.step() == 0
+    G, mask = o.g(), o.trusted_mask()
+    inner = mask.copy()           # element and its eight neighbours final
+    M = np.pad(mask, 1)
+    for dx in range(3):
+        for dy in range(3):
+            inner &= M[dx:dx + size, dy:dy + size]
+    assert inner.sum() > 1_000_000
+    F0, F1 = _dfm_operators(G, cost, (int(goal[0]), int(goal[1])))
+    assert int((F1[inner] != G[inner]).sum()) == 0
+    n0 = int((F0[inner] != G[inner]).sum())
+    assert 0 < n0 < 2000 and np.all(F0[inner] >= G[inner])      # measured: 259, each one ulp above

@@ -22,6 +22,8 @@ SYMBOLS = [
     "ufm_batch_set_start", "ufm_batch_set_goal", "ufm_batch_reset", "ufm_batch_step",
     "ufm_batch_read_field", "ufm_extract_path", "ufm_batch_extract_path", "ufm_read_info",
     "ufm_check_layout", "ufm_batch_check_layout", "ufm_batch_set_param",
+    "ufm_batch_create_sharded", "ufm_batch_shards", "ufm_batch_set_heuristic_multiplier", "ufm_batch_set_map_device",
+    "ufm_batch_patch_map_device", "ufm_batch_read_map", "ufm_batch_set_profiling", "ufm_batch_stream",
 ]
 
 
@@ -43,6 +45,8 @@ class Stats(C.Structure):
         ("queued_raise", C.c_uint32),
         ("timed_launches", C.c_uint32),
         ("timed_raise_launches", C.c_uint32),
+        ("graphs_instantiated", C.c_uint32),
+        ("reserved0", C.c_uint32),
     ]
 
     def as_dict(self):
@@ -102,6 +106,15 @@ def load_library():
     L.ufm_stream.restype = vp
     L.ufm_version.restype = C.c_char_p
     L.ufm_batch_create.argtypes = [C.POINTER(vp), i, i, i, i, i]
+    L.ufm_batch_create_sharded.argtypes = [C.POINTER(vp), i, i, i, i, C.POINTER(i), i]
+    L.ufm_batch_shards.argtypes = [vp]
+    L.ufm_batch_set_heuristic_multiplier.argtypes = [vp, f]
+    L.ufm_batch_set_map_device.argtypes = [vp, i, vp, i, i]
+    L.ufm_batch_patch_map_device.argtypes = [vp, i, vp, i, i, i, i]
+    L.ufm_batch_read_map.argtypes = [vp, i, vp]
+    L.ufm_batch_set_profiling.argtypes = [vp, i]
+    L.ufm_batch_stream.argtypes = [vp, i]
+    L.ufm_batch_stream.restype = vp
     L.ufm_batch_destroy.argtypes = [vp]
     L.ufm_batch_size.argtypes = [vp]
     L.ufm_batch_set_occupancy_threshold.argtypes = [vp, f]
@@ -258,12 +271,18 @@ class Planner:
 
 
 class BatchPlanner:
-    """Batch of independent, equally sized map instances on one device."""
+    """Batch of independent, equally sized map instances: on one device, or (devices=[...]) spread over several
+    in contiguous blocks, one engine per device inside the one handle."""
 
-    def __init__(self, n_maps, algo, opt_lvl=0, use_heuristic=False, device=0):
+    def __init__(self, n_maps, algo, opt_lvl=0, use_heuristic=False, device=0, devices=None):
         self.L = load_library()
         h = C.c_void_p()
-        _chk(self.L.ufm_batch_create(C.byref(h), n_maps, algo, opt_lvl, int(use_heuristic), device), "ufm_batch_create")
+        if devices is None:
+            _chk(self.L.ufm_batch_create(C.byref(h), n_maps, algo, opt_lvl, int(use_heuristic), device), "ufm_batch_create")
+        else:
+            arr = (C.c_int * len(devices))(*devices)
+            _chk(self.L.ufm_batch_create_sharded(C.byref(h), n_maps, algo, opt_lvl, int(use_heuristic), arr, len(devices)),
+                 "ufm_batch_create_sharded")
         self.h = h
         self.n = n_maps
         self.algo = algo
@@ -289,10 +308,34 @@ class BatchPlanner:
         _chk(self.L.ufm_batch_set_map(self.h, i, m.ctypes.data, width, length), "ufm_batch_set_map")
         self._dims = (length + (0 if self.algo == ALGO_DFM else 1), width + (0 if self.algo == ALGO_DFM else 1))
 
+    def set_map_device(self, i, dev_ptr, width, length):
+        _chk(self.L.ufm_batch_set_map_device(self.h, i, dev_ptr, width, length), "ufm_batch_set_map_device")
+        self._dims = (length + (0 if self.algo == ALGO_DFM else 1), width + (0 if self.algo == ALGO_DFM else 1))
+
     def patch_map(self, i, patch, x, y):
         patch = np.ascontiguousarray(patch, dtype=np.uint8)
         h, w = patch.shape
         _chk(self.L.ufm_batch_patch_map(self.h, i, patch.ctypes.data, int(x), int(y), w, h), "ufm_batch_patch_map")
+
+    def patch_map_device(self, i, dev_ptr, x, y, w, h):
+        _chk(self.L.ufm_batch_patch_map_device(self.h, i, dev_ptr, int(x), int(y), int(w), int(h)), "ufm_batch_patch_map_device")
+
+    def set_heuristic_multiplier(self, m):
+        _chk(self.L.ufm_batch_set_heuristic_multiplier(self.h, float(m)), "ufm_batch_set_heuristic_multiplier")
+
+    def set_profiling(self, on):
+        _chk(self.L.ufm_batch_set_profiling(self.h, int(on)), "ufm_batch_set_profiling")
+
+    def stream_ptr(self, shard=0):
+        return int(self.L.ufm_batch_stream(self.h, shard) or 0)
+
+    def shards(self):
+        return self.L.ufm_batch_shards(self.h)
+
+    def read_map(self, i, width, length):
+        m = np.empty((length, width), dtype=np.uint8)
+        _chk(self.L.ufm_batch_read_map(self.h, i, m.ctypes.data), "ufm_batch_read_map")
+        return m
 
     def set_start(self, i, x, y):
         _chk(self.L.ufm_batch_set_start(self.h, i, float(x), float(y)), "ufm_batch_set_start")

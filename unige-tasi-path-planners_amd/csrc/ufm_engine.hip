@@ -25,10 +25,13 @@
 
 #include <chrono>
 #include <cmath>
+#include <cstddef>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <new>
+#include <type_traits>
+#include <thread>
 #include <vector>
 
 #include "../../include/ufm.h"
@@ -57,6 +60,14 @@ constexpr int NTHR = 1024;     // 16 waves; four lanes per node, each wave owns 
 #endif
 #ifndef UFM_DFM_QUIET_VISITS
 #define UFM_DFM_QUIET_VISITS 24   // DFM: ... and a decrease of <= 4 ulp no longer wakes the neighbours
+#endif
+// Level 1 (ALGO_DFM1) converges without such cut-offs on almost every map; they are its livelock guard only: block
+// Gauss-Seidel between two tiles can cycle through a finite set of last-bit states (2048^2, seed 1006)
+#ifndef UFM_DFM1_LAX_VISITS
+#define UFM_DFM1_LAX_VISITS 64
+#endif
+#ifndef UFM_DFM1_QUIET_VISITS
+#define UFM_DFM1_QUIET_VISITS 96
 #endif
 #ifndef UFM_DPP_MIN_ASM
 #define UFM_DPP_MIN_ASM 1
@@ -96,6 +107,16 @@ constexpr int CTS = ((T + 1) * (T + 1) + 127) / 128 * 128;       // bytes per co
 constexpr float SQRT2F = 1.41421356237309504880168872420969807856967187537694f;  // Macros.cpp:2
 
 enum { MODE_LOWER = 0, MODE_RAISE = 1 };
+// Kernel-side operator ids: the three planner families of include/ufm.h plus the level-1 form of MS-DFM.
+// DFMPlanner<1> never evaluates min_rhs<0>'s "best cell of each pair, then one quadratic per stencil" while it
+// lowers: every expansion offers each neighbour ONE candidate built on the expanded cell itself
+// (min_rhs_decreased_neighbor, DynamicFastMarching_impl.h:270-313) and RHS keeps the smallest (plan<1> :79-86).
+// Its consistent field is therefore the fixed point of "min over the eight per-neighbour candidates" -- which
+// is not the level-0 operator at the ulp level: the float quadratic is not monotone, so Q(min(a,b), .) and
+// min(Q(a, .), Q(b, .)) differ in the last bit where two fronts meet.  Measured on the oracle's 1024^2 field:
+// 0 of 1.02 M interior elements violate G = F1(G), 259 violate G = F0(G).
+constexpr int ALGO_DFM1 = 3;
+template <int ALGO> constexpr bool is_dfm = (ALGO == UFM_ALGO_DFM || ALGO == ALGO_DFM1);
 
 constexpr int LMAX = 8192;
 constexpr int INFBITS = 0x7F800000;   // +inf as int: non-negative floats order like their bits
@@ -132,6 +153,16 @@ struct DevCounters {
     unsigned long long raise_visits;   // tile visits of the invalidation kernel (subset of tile_visits)
 };
 
+// Per-step scalars the kernels read from memory, not from their by-value parameter block: the replans are
+// replayed from captured graphs whose kernel arguments are frozen, and the reference's harness sends a new
+// heuristic multiplier with every move (Tests/Planners/DFM/main.cpp:111-112).
+struct DevDyn {
+    float hm;                   // heuristic multiplier of the keys (0 when built like -DNO_HEURISTIC)
+    int thr;                    // Graph::occupancy_threshold_uchar_
+    int focused;                // honour the reference's end condition (stop at the start's key)
+    int pad;
+};
+
 struct DevParams {
     float *G;                   // [NT][T][T] tile-major; elements of a tile beyond the map stay +inf
     float *Gprev;               // snapshot of a tile at its first touch in a step (same layout)
@@ -151,10 +182,10 @@ struct DevParams {
     int *prio;                  // [2 queues][2][NT] float bits: smallest value that entered the tile since its last visit
     int *start;                 // [nmaps][4] start elements (linear index in the map, -1 unused)
     float *bnd;                 // [nmaps] k_start_bound output
-    int focused;                // honour the reference's end condition (stop at the start's key)
-    float hm;                   // heuristic multiplier of the keys (0 when built like -DNO_HEURISTIC)
+    DevDyn *dyn;                // heuristic multiplier, occupancy threshold, focused flag (see DevDyn)
     float *spos;                // [nmaps][2] start position (FD/SG: Position; DFM: start cell indices)
-    int *touched;               // [NT]
+    int *touched;               // [NT] visits of the tile in the current step
+    uint8_t *fresh;             // [NT] the tile held nothing but +inf when the step first touched it (no Gprev snapshot taken)
     int *tlist;                 // [NT]
     int *sflag;                 // [NT] pending seeds (from patches)
     int *slist;                 // [NT]
@@ -168,7 +199,6 @@ struct DevParams {
     int L, W;                   // cells per map
     int TX, TY, NTm, NT, nmaps;
     int cells;                  // elements are cells (DFM), not nodes
-    int thr;                    // Graph::occupancy_threshold_uchar_
     size_t gstride;             // floats per map in G (= NTm * T * T)
     size_t cstride;             // bytes per map in cost
     size_t mstride;             // bytes per map in mark
@@ -208,25 +238,26 @@ __device__ __host__ __forceinline__ size_t gaddr(const DevParams &P, int m, int 
 // among the start elements that have been reached; +inf while none has.
 __device__ __forceinline__ float start_bound(const DevParams &P, int m) {
     float b = 0.0f;
-    const float sx = P.spos[2 * m], sy = P.spos[2 * m + 1];
+    const float sx = P.spos[2 * m], sy = P.spos[2 * m + 1], hm = P.dyn->hm;
     for (int i = 0; i < 4; ++i) {
         const int e = P.start[4 * m + i];
         if (e < 0) continue;
         const int x = e / P.EY, y = e - x * P.EY;
         const float g = __hip_atomic_load(&P.G[gaddr(P, m, x, y)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         // heuristic keys (FD impl:178-186, DFM impl:146-155): first component k + hm * dist(start, s)
-        if (g < INFINITY) b = fmaxf(b, g + P.hm * hypotf(sx - (float)x, sy - (float)y));
+        if (g < INFINITY) b = fmaxf(b, g + hm * hypotf(sx - (float)x, sy - (float)y));
     }
     return b > 0.0f ? b : INFINITY;
 }
 // admissible lower bound of hm * dist(start, s) over the elements s of a tile: with heuristic keys
 // an element is only worth relaxing while value + hm * dist < the start's key
 __device__ __forceinline__ float tile_heuristic(const DevParams &P, int m, int tx, int ty) {
-    if (P.hm == 0.0f) return 0.0f;
+    const float hm = P.dyn->hm;
+    if (hm == 0.0f) return 0.0f;
     const float sx = P.spos[2 * m], sy = P.spos[2 * m + 1];
     const float x0 = (float)(tx * T), x1 = (float)(tx * T + T - 1), y0 = (float)(ty * T), y1 = (float)(ty * T + T - 1);
     const float dx = fmaxf(fmaxf(x0 - sx, sx - x1), 0.0f), dy = fmaxf(fmaxf(y0 - sy, sy - y1), 0.0f);
-    return P.hm * hypotf(dx, dy) * 0.999f;   // (0.999: stay below the reference's own float rounding of the distance)
+    return hm * hypotf(dx, dy) * 0.999f;   // (0.999: stay below the reference's own float rounding of the distance)
 }
 
 // ---- optional in-kernel timing of tile visits (-DUFM_TIMING, diagnostic builds only) -------
@@ -353,6 +384,16 @@ template <> struct QuadConsts<UFM_ALGO_DFM> {
         th = (q & 1) ? tau * SQRT2F : tau;
     }
 };
+template <> struct QuadConsts<ALGO_DFM1> {
+    float th;   // lanes 0, 1: cost (h = 1); lanes 2, 3: cost*SQRT2 (= cost * HYPOT(+-1, +-1))
+    int so, po; // LDS offsets: +-so = the lane's two neighbours, +-po = the perpendicular pair of the same stencil
+    __device__ __forceinline__ void load(const float *Cs, int lx, int ly, int q) {
+        const float tau = Cs[lx * CP + ly];
+        th = (q & 2) ? tau * SQRT2F : tau;
+        so = (q == 0) ? GP : (q == 1) ? 1 : (q == 2) ? GP - 1 : GP + 1;   // vertical | horizontal | TR-BL | TL-BR
+        po = (q == 0) ? 1 : (q == 1) ? GP : (q == 2) ? GP + 1 : GP - 1;   // (dx != dy -> TL/BR pair, dx == dy -> BL/TR pair, impl:284-296)
+    }
+};
 template <> struct QuadConsts<UFM_ALGO_SG> {
     CellSG k;
     __device__ __forceinline__ void load(const float *Cs, int lx, int ly, int q) {
@@ -405,6 +446,11 @@ __device__ __forceinline__ float eval_quad(const float *ctr, int q, const QuadCo
             r = q_dfm(fminf(ctr[a], ctr[b]), fminf(ctr[c], ctr[d]), C.th);
         }
         return r;
+    } else if constexpr (ALGO == ALGO_DFM1) {
+        // DynamicFastMarching_impl.h:270-313 for the two neighbours of this lane's axis: g_a = G(nbr), g_b = the
+        // better cell of the perpendicular pair; RHS = the smallest of the eight candidates (plan<1> :79-86)
+        const float pm = fminf(ctr[-C.po], ctr[C.po]);
+        return fminf(q_dfm(ctr[-C.so], pm, C.th), q_dfm(ctr[C.so], pm, C.th));
     } else {
         const int sx = (q & 2) ? GP : -GP, sy = (q & 1) ? 1 : -1;
         const float gD = ctr[sx + sy], gV = ctr[sx], gH = ctr[sy];
@@ -489,19 +535,20 @@ __global__ __launch_bounds__(NTHR, UFM_RELAX_WAVES) void k_relax(DevParams P, in
         if (DYN) { P.ctr->rel[Q][r] = n; if (n) P.ctr->last_work[Q] = k; }
     }
     if (n == 0) return;
+    const int focused = P.dyn->focused, thr = P.dyn->thr;
     UFM_TICK(tkb);
     const int *cand = P.cand + (size_t)(Q * 3 + r) * P.NT;
     int *prio = P.prio + (size_t)(Q * 2 + pc) * P.NT;
     int *queued = P.queued + (size_t)(Q * 2 + pc) * P.NT;
-    constexpr int CROWS = (ALGO == UFM_ALGO_DFM) ? T : T + 1;
-    constexpr int COFF = (ALGO == UFM_ALGO_DFM) ? 0 : 1;
+    constexpr int CROWS = is_dfm<ALGO> ? T : T + 1;
+    constexpr int COFF = is_dfm<ALGO> ? 0 : 1;
 
     if (tid == 0) s_min = INFBITS;
     // the list -> priority loads of the scan below are issued before the start keys are waited for: the two
     // chains of dependent loads (start elements -> G, list -> priority) run side by side instead of in series
     int c_first = 0, pb_first = INFBITS;
     if (!DYN && MODE == MODE_LOWER && tid < n) { c_first = cand[tid]; pb_first = prio[c_first]; }
-    if (!DYN && tid < 64) s_B[tid] = (MODE == MODE_LOWER && P.focused && tid < P.nmaps) ? start_bound(P, tid) : INFINITY;
+    if (!DYN && tid < 64) s_B[tid] = (MODE == MODE_LOWER && focused && tid < P.nmaps) ? start_bound(P, tid) : INFINITY;
     __syncthreads();
     if (!DYN && MODE == MODE_LOWER) {   // smallest priority among the entries that are not parked beyond their map's start key
         // (invalidation is order-free -- delta = +inf --: no band, no scan, two dependent loads less per launch)
@@ -558,8 +605,8 @@ __global__ __launch_bounds__(NTHR, UFM_RELAX_WAVES) void k_relax(DevParams P, in
             if (MODE == MODE_LOWER) {
                 // (the start key as of the beginning of the launch, s_B: re-reading the start elements for
                 //  every tile put two more dependent memory round trips before each visit)
-                const float B = P.focused ? (m < 64 ? s_B[m] : start_bound(P, m)) : INFINITY;
-                const float hd = P.focused ? tile_heuristic(P, m, t / P.TY, t % P.TY) : 0.0f;
+                const float B = focused ? (m < 64 ? s_B[m] : start_bound(P, m)) : INFINITY;
+                const float hd = focused ? tile_heuristic(P, m, t / P.TY, t % P.TY) : 0.0f;
                 parked = !(__int_as_float(pbits) + hd < B || B == INFINITY);
                 release = !(__int_as_float(pbits) > theta) && !parked;
             } else {
@@ -617,7 +664,7 @@ __global__ __launch_bounds__(NTHR, UFM_RELAX_WAVES) void k_relax(DevParams P, in
             const int cr = e / CROWS, cc = e - cr * CROWS;
             const int cx = x0 + cr - COFF, cy = y0 + cc - COFF;
             const int c = (e == tid) ? c0 : ct[e];
-            Cs[cr * CP + cc] = (cx < 0 || cy < 0 || cx >= P.L || cy >= P.W || c >= P.thr) ? INFINITY : (float)c;
+            Cs[cr * CP + cc] = (cx < 0 || cy < 0 || cx >= P.L || cy >= P.W || c >= thr) ? INFINITY : (float)c;
         }
         __syncthreads();
         UFM_TICK(tk1);
@@ -626,7 +673,12 @@ __global__ __launch_bounds__(NTHR, UFM_RELAX_WAVES) void k_relax(DevParams P, in
         const int dbg_rank = P.rank[gt];
         const int dbg_ninf0 = __syncthreads_count(io_on && gl0 == INFINITY);
 #endif
-        if (s_misc[0] && io_on) P.Gprev[(size_t)gt * TT + tid] = gl0;
+        if (s_misc[0]) {   // first touch of the tile in this step: snapshot for num_nodes_expanded -- unless there is nothing
+            // to remember (a plan's tiles hold only +inf: 1 KB of writes per tile and as many reads at the end saved)
+            const int any = __syncthreads_or(io_on && gl0 != INFINITY);
+            if (any && io_on) P.Gprev[(size_t)gt * TT + tid] = gl0;
+            if (tid == 0) P.fresh[gt] = any ? 0 : 1;
+        }
 
         // per-lane constants of the wave's four patches
         QuadConsts<ALGO> C[PPW];
@@ -658,7 +710,7 @@ __global__ __launch_bounds__(NTHR, UFM_RELAX_WAVES) void k_relax(DevParams P, in
         // (4-colouring: no two 8-neighbours share one).
         int cnt[PPW] = {};
         int tot = 0;
-        const bool lax = (ALGO == UFM_ALGO_DFM) && (s_misc[1] > UFM_DFM_LAX_VISITS);
+        const bool lax = is_dfm<ALGO> && (s_misc[1] > (ALGO == ALGO_DFM1 ? UFM_DFM1_LAX_VISITS : UFM_DFM_LAX_VISITS));
         bool conv = false;
 #ifdef UFM_TIMING
         const bool wtrace_on = DYN && MODE == MODE_LOWER && k == UFM_TRACE_K0 && i == 0;
@@ -693,11 +745,11 @@ __global__ __launch_bounds__(NTHR, UFM_RELAX_WAVES) void k_relax(DevParams P, in
                             // (seen on 2048^2).  In a tile that keeps coming back (`lax`, > 16 visits in one
                             // step) a rise of 1 ulp is treated as rounding noise and left alone; everywhere
                             // else the relaxation stays exact.
-                            if (ALGO == UFM_ALGO_DFM && lax) want = want & !((nv > g) & (nv < INFINITY) & (__float_as_int(nv) - __float_as_int(g) <= 1));
+                            if (is_dfm<ALGO> && lax) want = want & !((nv > g) & (nv < INFINITY) & (__float_as_int(nv) - __float_as_int(g) <= 1));
                             doit = want & ((nv < g) | (colour == (cnt[j] & 3)));
                         } else {
                             // value lost its support (DFM: by more than the 8 ulp its neighbours may be stale)
-                            if (ALGO == UFM_ALGO_DFM) want = (g < INFINITY) & (nv > g) & ((nv == INFINITY) | (__float_as_int(nv) - __float_as_int(g) > 8));
+                            if (is_dfm<ALGO>) want = (g < INFINITY) & (nv > g) & ((nv == INFINITY) | (__float_as_int(nv) - __float_as_int(g) > 8));
                             else want = (g < INFINITY) & (nv > g);
                             doit = want;
                             nv = INFINITY;
@@ -709,7 +761,7 @@ __global__ __launch_bounds__(NTHR, UFM_RELAX_WAVES) void k_relax(DevParams P, in
                         const unsigned long long mask = __builtin_amdgcn_ballot_w64(gn != g);   // = doit
                         unsigned long long wanted;                                               // lanes not yet settled
                         if (MODE == MODE_RAISE) wanted = mask;
-                        else if (ALGO == UFM_ALGO_DFM) wanted = __builtin_amdgcn_ballot_w64(want);
+                        else if (is_dfm<ALGO>) wanted = __builtin_amdgcn_ballot_w64(want);
                         else wanted = __builtin_amdgcn_fcmpf(nv, g, 14);   // lanes with nv != g (14 = FCMP_UNE), as a v_cmp into an SGPR pair
                         g = gn;
                         UFM_SWEEP_FENCE();                               // value before wake bit
@@ -777,9 +829,12 @@ __global__ __launch_bounds__(NTHR, UFM_RELAX_WAVES) void k_relax(DevParams P, in
             // new information) is stored but does not wake the neighbour; after 24 visits of a tile in
             // one step the same holds for decreases.  Well inside DFM's 1e-6 tolerance.
             bool significant = true;
-            if (ALGO == UFM_ALGO_DFM && MODE == MODE_LOWER && gf < INFINITY && gl0 < INFINITY) {
+            if (is_dfm<ALGO> && MODE == MODE_LOWER && gf < INFINITY && gl0 < INFINITY) {
                 const int du = __float_as_int(gf) - __float_as_int(gl0);
-                if (du > 0 ? du <= 4 : (s_misc[1] > UFM_DFM_QUIET_VISITS && du >= -4)) significant = false;
+                // (level 1: only in a tile that keeps coming back -- the rises of its operator are corrections of
+                //  values latched from transient neighbours and have to travel)
+                if (ALGO == UFM_ALGO_DFM ? (du > 0 ? du <= 4 : (s_misc[1] > UFM_DFM_QUIET_VISITS && du >= -4))
+                                         : (s_misc[1] > UFM_DFM1_QUIET_VISITS && du >= -4 && du <= 4)) significant = false;
             }
             // priority handed to a neighbour: the new value (lowering) / the value that was
             // invalidated (raising: the reference's key of an under-consistent element, min(g,rhs) = g)
@@ -882,7 +937,8 @@ __global__ void k_triage(DevParams P, int k, float delta, float rbound) {
     // start keys of the first 64 maps once per workgroup: their loads (start elements -> G) then run
     // beside the list -> priority chain instead of behind it
     __shared__ float s_B[64];
-    if (MODE == MODE_LOWER && P.focused) {
+    const int focused = P.dyn->focused;
+    if (MODE == MODE_LOWER && focused) {
         if (threadIdx.x < 64 && (int)threadIdx.x < P.nmaps) s_B[threadIdx.x] = start_bound(P, threadIdx.x);
         __syncthreads();
     }
@@ -897,8 +953,8 @@ __global__ void k_triage(DevParams P, int k, float delta, float rbound) {
         bool release = false, parked = false;
         if (valid) {
             if (MODE == MODE_LOWER) {
-                const float B = P.focused ? (m < 64 ? s_B[m] : start_bound(P, m)) : INFINITY;
-                const float hd = P.focused ? tile_heuristic(P, m, t / P.TY, t % P.TY) : 0.0f;
+                const float B = focused ? (m < 64 ? s_B[m] : start_bound(P, m)) : INFINITY;
+                const float hd = focused ? tile_heuristic(P, m, t / P.TY, t % P.TY) : 0.0f;
                 parked = !(__int_as_float(pbits) + hd < B || B == INFINITY);
                 release = !(__int_as_float(pbits) > theta) && !parked;
             } else {
@@ -1066,8 +1122,8 @@ __device__ void unpark(const DevParams &P, int qz, int k, float rbound, int &s_k
         const int m = gt / P.NTm, t = gt - m * P.NTm;
         bool in;
         if (qz == Q_LOWER) {
-            const float B = P.focused ? start_bound(P, m) : INFINITY;
-            const float hd = P.focused ? tile_heuristic(P, m, t / P.TY, t % P.TY) : 0.0f;
+            const float B = P.dyn->focused ? start_bound(P, m) : INFINITY;
+            const float hd = P.dyn->focused ? tile_heuristic(P, m, t / P.TY, t % P.TY) : 0.0f;
             in = (__int_as_float(pbits) + hd < B || B == INFINITY);
         } else {
             in = !(__int_as_float(pbits) > rb);
@@ -1119,7 +1175,7 @@ __global__ void k_step_begin(DevParams P, StepBegin a) { step_begin(P, a); }
 __device__ __forceinline__ void prepare_bound(const DevParams &P, float margin) {
     float b = 0.0f;
     for (int m = 0; m < P.nmaps; ++m) b = fmaxf(b, start_bound(P, m));
-    P.ctr->rbound = P.focused ? b + margin : INFINITY;
+    P.ctr->rbound = P.dyn->focused ? b + margin : INFINITY;
     P.ctr->done = 0;
 }
 __global__ void k_prepare_bound(DevParams P, float margin) {
@@ -1148,7 +1204,7 @@ __device__ int replan_check(const DevParams &P, int kr, int kl, float margin, bo
         for (int m = 0; m < P.nmaps; ++m) bnew = fmaxf(bnew, start_bound(P, m));
         const bool raise_done = P.ctr->cnt[Q_RAISE][kr % 3] == 0 || P.ctr->rel[Q_RAISE][(kr + 2) % 3] == 0;
         const bool lower_done = P.ctr->cnt[Q_LOWER][kl % 3] == 0 || P.ctr->rel[Q_LOWER][(kl + 2) % 3] == 0;
-        const bool again = P.focused && (__int_as_float(s_m) < bnew);
+        const bool again = P.dyn->focused && (__int_as_float(s_m) < bnew);
         const int done = (raise_done && lower_done && !again) ? 1 : 0;
         s_done = done;
         if (record) {
@@ -1167,6 +1223,7 @@ __global__ void k_check(DevParams P, int kr, int kl, float margin) {
     __shared__ int s_m, s_done;
     replan_check(P, kr, kl, margin, true, s_m, s_done);
 }
+__global__ void k_set_dyn(DevDyn *dst, DevDyn v) { *dst = v; }
 __global__ void k_start_bound(DevParams P) {
     const int m = blockIdx.x * blockDim.x + threadIdx.x;
     if (m < P.nmaps) P.bnd[m] = start_bound(P, m);
@@ -1228,7 +1285,7 @@ __device__ __forceinline__ void finalize_tiles(const DevParams &P) {
     for (int i = blockIdx.x; i < n; i += gridDim.x) {
         const int gt = P.tlist[i];
         const size_t gidx = (size_t)gt * TT + threadIdx.x;
-        const int diff = (threadIdx.x < T * T) && (P.G[gidx] != P.Gprev[gidx]);
+        const int diff = (threadIdx.x < T * T) && (P.fresh[gt] ? (P.G[gidx] != INFINITY) : (P.G[gidx] != P.Gprev[gidx]));
         const int c = __syncthreads_count(diff);
         if (threadIdx.x == 0) {
             if (c) atomicAdd(&P.ctr->expanded, (unsigned long long)c);
@@ -1249,8 +1306,13 @@ __global__ __launch_bounds__(256) void k_finalize(DevParams P, int only_if_done)
         const int gt = P.tlist[i];
         const float *g = P.G + (size_t)gt * TT, *g0 = P.Gprev + (size_t)gt * TT;
         int c = 0;
+        if (P.fresh[gt]) {
 #pragma unroll
-        for (int e = lane; e < TT; e += 64) c += (g[e] != g0[e]) ? 1 : 0;
+            for (int e = lane; e < TT; e += 64) c += (g[e] != INFINITY) ? 1 : 0;
+        } else {
+#pragma unroll
+            for (int e = lane; e < TT; e += 64) c += (g[e] != g0[e]) ? 1 : 0;
+        }
         total += (unsigned long long)c;
         if (lane == 0) P.touched[gt] = 0;
     }
@@ -1306,7 +1368,7 @@ __global__ __launch_bounds__(1024) void k_replan_begin(DevParams P, ReplanBegin 
     replan_begin(P, a, s_keep);
 }
 // first node of the replan graph: the per-replan inputs come from host-coherent memory
-struct ReplanJob { ReplanBegin rb; int k_lower; unsigned int seq; };
+struct ReplanJob { ReplanBegin rb; int k_lower; unsigned int seq; DevDyn dyn; };
 __global__ __launch_bounds__(1024) void k_replan_begin_job(DevParams P, const ReplanJob *job) {
     __shared__ int s_keep;
     __shared__ ReplanJob s_job;
@@ -1315,7 +1377,9 @@ __global__ __launch_bounds__(1024) void k_replan_begin_job(DevParams P, const Re
     __syncthreads();
     if (threadIdx.x == 0) {
         P.ctr->kbase[Q_RAISE] = s_job.rb.k_raise; P.ctr->kbase[Q_LOWER] = s_job.k_lower; P.ctr->pubseq = s_job.seq;
+        *P.dyn = s_job.dyn;          // this workgroup reads it back below (prepare_bound, unpark), the later kernels from memory
     }
+    __syncthreads();
     replan_begin(P, s_job.rb, s_keep);
 }
 // ... and between the invalidation and the lowering launches
@@ -1354,6 +1418,8 @@ struct Engine {
     int algo = 0, opt_lvl = 0, heur = 0, device = 0, nmaps = 1;
     float heuristic_multiplier = 1.0f;
     int thr_uchar = 254;             // Graph.h:34
+    DevDyn dyn_dev{-1.0f, -1, -1, 0};  // what *P.dyn holds (as far as the host knows)
+    uint32_t graphs_made = 0;        // replan graphs instantiated so far (ufm_stats::graphs_instantiated)
     int W = 0, L = 0;
     DevParams P{};
     bool allocated = false;
@@ -1384,6 +1450,8 @@ struct Engine {
     uint8_t *h_patch = nullptr;      // pinned staging
     float *d_field = nullptr;        // ufm_read_field: the requested window, dense
     size_t d_field_cap = 0;
+    int32_t *d_info = nullptr;       // ufm_read_info: back-pointers of the requested window
+    size_t d_info_cap = 0;           // (int32 entries)
     uint8_t *d_pmask = nullptr;      // changed-cell mask of the patch being applied
     size_t d_pmask_cap = 0;
     PathJob *d_jobs = nullptr, *h_jobs = nullptr;     // path extraction: per-map start / goal (h_: pinned)
@@ -1429,10 +1497,15 @@ struct Engine {
 
 void Engine::release() {
     if (!allocated) return;
-    hipFree(P.G); hipFree(P.Gprev); hipFree(P.ring); hipFree(P.cost); hipFree(P.costT); hipFree(P.goal); hipFree(P.cand); hipFree(P.ready); hipFree(P.hint); hipFree(P.rank); hipFree(P.park); hipFree(P.pflag); hipFree(P.pprio); hipFree(P.queued); hipFree(P.prio); hipFree(P.start); hipFree(P.bnd); hipFree(P.spos);
-    hipFree(P.touched); hipFree(P.tlist); hipFree(P.sflag); hipFree(P.slist); hipFree(P.slist2);
-    hipFree(P.mark); hipFree(P.num_updated); hipFree(P.consume); hipFree(P.lmax); hipFree(P.ctr);
-    hipFree(d_scratch);
+    if (stream) hipStreamSynchronize(stream);
+    drop_graphs();                       // captured kernel arguments hold these pointers
+    std::memset(&graph_sig, 0, sizeof(graph_sig));
+    void *ptrs[] = {P.G, P.Gprev, P.ring, P.cost, P.costT, P.goal, P.cand, P.ready, P.hint, P.rank, P.park, P.pflag, P.pprio,
+                    P.queued, P.prio, P.start, P.bnd, P.dyn, P.spos, P.touched, P.fresh, P.tlist, P.sflag, P.slist, P.slist2,
+                    P.mark, P.num_updated, P.consume, P.lmax, P.ctr, d_scratch};
+    for (void *q : ptrs) if (q) hipFree(q);
+    P = DevParams{};                     // every pointer null again: a failed alloc() can be released, and released twice
+    d_scratch = nullptr;
     allocated = false;
 }
 
@@ -1445,6 +1518,8 @@ int Engine::alloc(int width, int length) {
     P.EY = nodes ? W + 1 : W;
     P.TX = (P.EX + T - 1) / T;
     P.TY = (P.EY + T - 1) / T;
+    // tile ids are ints; the element count of a map must fit one as well (start elements, marks)
+    if ((long long)P.TX * P.TY * nmaps > (long long)INT32_MAX / 4 || (long long)P.EX * P.EY > INT32_MAX) return UFM_ERR_NOMEM;
     P.NTm = P.TX * P.TY;
     P.nmaps = nmaps;
     P.NT = P.NTm * nmaps;
@@ -1452,54 +1527,70 @@ int Engine::alloc(int width, int length) {
     P.gstride = (size_t)P.NTm * TT;
     P.cstride = (size_t)L * W;
     P.mstride = (size_t)P.EX * P.EY;
-    P.thr = thr_uchar;
+    allocated = true;                    // from here on release() has something to free, also after a failure half way
     const size_t gbytes = P.gstride * nmaps * sizeof(float);
-    HIPCHK(hipMalloc(&P.G, gbytes));
-    HIPCHK(hipMalloc(&P.Gprev, gbytes));
-    HIPCHK(hipMalloc(&P.ring, (size_t)P.NT * RING * sizeof(float)));
-    HIPCHK(hipMalloc(&P.cost, P.cstride * nmaps));
-    HIPCHK(hipMalloc(&P.costT, (size_t)P.NT * CTS));
-    HIPCHK(hipMalloc(&P.goal, sizeof(int) * 2 * nmaps));
-    HIPCHK(hipMalloc(&P.cand, sizeof(int) * 6 * P.NT));
-    HIPCHK(hipMalloc(&P.ready, sizeof(int) * P.NT));
-    HIPCHK(hipMalloc(&P.hint, sizeof(int) * P.NT));
-    HIPCHK(hipMalloc(&P.rank, sizeof(int) * P.NT));
-    HIPCHK(hipMemsetAsync(P.rank, 0, sizeof(int) * P.NT, stream));
-
-    HIPCHK(hipMemsetAsync(P.hint, 0, sizeof(int) * P.NT, stream));
-    HIPCHK(hipMalloc(&P.park, sizeof(int) * 4 * P.NT));
-    HIPCHK(hipMalloc(&P.pflag, sizeof(int) * 2 * P.NT));
-    HIPCHK(hipMalloc(&P.pprio, sizeof(int) * 2 * P.NT));
-    HIPCHK(hipMalloc(&P.queued, sizeof(int) * 4 * P.NT));
-    HIPCHK(hipMalloc(&P.prio, sizeof(int) * 4 * P.NT));
-    HIPCHK(hipMalloc(&P.start, sizeof(int) * 4 * nmaps));
-    HIPCHK(hipMalloc(&P.bnd, sizeof(float) * nmaps));
-    HIPCHK(hipMalloc(&P.spos, sizeof(float) * 2 * nmaps));
-    HIPCHK(hipMemsetAsync(P.spos, 0, sizeof(float) * 2 * nmaps, stream));
-    HIPCHK(hipMemsetAsync(P.start, 0xFF, sizeof(int) * 4 * nmaps, stream));
-    HIPCHK(hipMalloc(&P.touched, sizeof(int) * P.NT));
-    HIPCHK(hipMalloc(&P.tlist, sizeof(int) * P.NT));
-    HIPCHK(hipMalloc(&P.sflag, sizeof(int) * P.NT));
-    HIPCHK(hipMalloc(&P.slist, sizeof(int) * P.NT));
-    HIPCHK(hipMalloc(&P.slist2, sizeof(int) * P.NT));
-    HIPCHK(hipMalloc(&P.mark, P.mstride * nmaps));
-    HIPCHK(hipMalloc(&P.num_updated, sizeof(unsigned int) * nmaps));
-    HIPCHK(hipMalloc(&P.consume, sizeof(int) * nmaps));
-    HIPCHK(hipMalloc(&P.lmax, sizeof(int) * LMAX));
-    HIPCHK(hipMalloc(&P.ctr, sizeof(DevCounters)));
-    HIPCHK(hipMalloc(&d_scratch, sizeof(int) * (4 * nmaps + 4)));
-    allocated = true;
-    HIPCHK(hipMemsetAsync(P.ctr, 0, sizeof(DevCounters), stream));
-    { int rc = reset_queues(); if (rc != UFM_OK) return rc; }
-    HIPCHK(hipMemsetAsync(P.touched, 0, sizeof(int) * P.NT, stream));
-    HIPCHK(hipMemsetAsync(P.sflag, 0, sizeof(int) * P.NT, stream));
-    HIPCHK(hipMemsetAsync(P.mark, 0, P.mstride * nmaps, stream));
-    HIPCHK(hipMemsetAsync(P.num_updated, 0, sizeof(unsigned int) * nmaps, stream));
-    HIPCHK(hipMemsetAsync(P.goal, 0xFF, sizeof(int) * 2 * nmaps, stream));
-    k_fill<<<1024, 256, 0, stream>>>(P.G, P.gstride * nmaps, INFINITY);
-    k_fill<<<1024, 256, 0, stream>>>(P.Gprev, P.gstride * nmaps, INFINITY);
-    k_fill<<<1024, 256, 0, stream>>>(P.ring, (size_t)P.NT * RING, INFINITY);
-    HIPCHK(hipGetLastError());
+    int rc = UFM_OK;
+    auto dmalloc = [&](auto *&ptr, size_t bytes) {
+        if (rc != UFM_OK) return;
+        void *q = nullptr;
+        const hipError_t e = hipMalloc(&q, bytes ? bytes : 1);
+        if (e != hipSuccess) { (void)hipGetLastError(); rc = (e == hipErrorOutOfMemory) ? UFM_ERR_NOMEM : UFM_ERR_HIP_BASE - (int)e; return; }
+        ptr = static_cast<std::remove_reference_t<decltype(ptr)>>(q);
+    };
+    dmalloc(P.G, gbytes);
+    dmalloc(P.Gprev, gbytes);
+    dmalloc(P.ring, (size_t)P.NT * RING * sizeof(float));
+    dmalloc(P.cost, P.cstride * nmaps);
+    dmalloc(P.costT, (size_t)P.NT * CTS);
+    dmalloc(P.goal, sizeof(int) * 2 * nmaps);
+    dmalloc(P.cand, sizeof(int) * 6 * P.NT);
+    dmalloc(P.ready, sizeof(int) * P.NT);
+    dmalloc(P.hint, sizeof(int) * P.NT);
+    dmalloc(P.rank, sizeof(int) * P.NT);
+    dmalloc(P.park, sizeof(int) * 4 * P.NT);
+    dmalloc(P.pflag, sizeof(int) * 2 * P.NT);
+    dmalloc(P.pprio, sizeof(int) * 2 * P.NT);
+    dmalloc(P.queued, sizeof(int) * 4 * P.NT);
+    dmalloc(P.prio, sizeof(int) * 4 * P.NT);
+    dmalloc(P.start, sizeof(int) * 4 * nmaps);
+    dmalloc(P.bnd, sizeof(float) * nmaps);
+    dmalloc(P.dyn, sizeof(DevDyn));
+    dmalloc(P.spos, sizeof(float) * 2 * nmaps);
+    dmalloc(P.touched, sizeof(int) * P.NT);
+    dmalloc(P.fresh, (size_t)P.NT);
+    dmalloc(P.tlist, sizeof(int) * P.NT);
+    dmalloc(P.sflag, sizeof(int) * P.NT);
+    dmalloc(P.slist, sizeof(int) * P.NT);
+    dmalloc(P.slist2, sizeof(int) * P.NT);
+    dmalloc(P.mark, P.mstride * nmaps);
+    dmalloc(P.num_updated, sizeof(unsigned int) * nmaps);
+    dmalloc(P.consume, sizeof(int) * nmaps);
+    dmalloc(P.lmax, sizeof(int) * LMAX);
+    dmalloc(P.ctr, sizeof(DevCounters));
+    dmalloc(d_scratch, sizeof(int) * (4 * nmaps + 4));
+    if (rc != UFM_OK) { release(); return rc; }
+    rc = [&]() -> int {
+        HIPCHK(hipMemsetAsync(P.rank, 0, sizeof(int) * P.NT, stream));
+        HIPCHK(hipMemsetAsync(P.hint, 0, sizeof(int) * P.NT, stream));
+        HIPCHK(hipMemsetAsync(P.spos, 0, sizeof(float) * 2 * nmaps, stream));
+        HIPCHK(hipMemsetAsync(P.start, 0xFF, sizeof(int) * 4 * nmaps, stream));
+        HIPCHK(hipMemsetAsync(P.ctr, 0, sizeof(DevCounters), stream));
+        { int rq = reset_queues(); if (rq != UFM_OK) return rq; }
+        HIPCHK(hipMemsetAsync(P.touched, 0, sizeof(int) * P.NT, stream));
+        HIPCHK(hipMemsetAsync(P.fresh, 0, (size_t)P.NT, stream));
+        HIPCHK(hipMemsetAsync(P.sflag, 0, sizeof(int) * P.NT, stream));
+        HIPCHK(hipMemsetAsync(P.mark, 0, P.mstride * nmaps, stream));
+        HIPCHK(hipMemsetAsync(P.num_updated, 0, sizeof(unsigned int) * nmaps, stream));
+        HIPCHK(hipMemsetAsync(P.goal, 0xFF, sizeof(int) * 2 * nmaps, stream));
+        k_fill<<<1024, 256, 0, stream>>>(P.G, P.gstride * nmaps, INFINITY);
+        k_fill<<<1024, 256, 0, stream>>>(P.Gprev, P.gstride * nmaps, INFINITY);
+        k_fill<<<1024, 256, 0, stream>>>(P.ring, (size_t)P.NT * RING, INFINITY);
+        dyn_dev = DevDyn{heur ? heuristic_multiplier : 0.0f, thr_uchar, focused ? 1 : 0, 0};
+        k_set_dyn<<<1, 1, 0, stream>>>(P.dyn, dyn_dev);
+        HIPCHK(hipGetLastError());
+        return UFM_OK;
+    }();
+    if (rc != UFM_OK) { release(); return rc; }
     pending.clear();
     for (auto &ms : maps) { ms.have_map = false; ms.initialize_search = true; }
     return UFM_OK;
@@ -1511,7 +1602,9 @@ int Engine::reset_queues() {
     k_fill<<<64, 256, 0, stream>>>(reinterpret_cast<float *>(P.prio), (size_t)4 * P.NT, INFINITY);
     HIPCHK(hipMemsetAsync(P.pflag, 0, sizeof(int) * 2 * P.NT, stream));
     k_fill<<<64, 256, 0, stream>>>(reinterpret_cast<float *>(P.pprio), (size_t)2 * P.NT, INFINITY);
-    HIPCHK(hipMemsetAsync(P.ctr->cnt, 0, sizeof(int) * 29, stream));   // cnt, rel, lmin, npark, nready, rcursor, nshort, last_work, fin_blocks
+    // the queue state at the head of DevCounters: cnt, rel, lmin, npark, nready, rcursor, nshort, last_work, fin_blocks
+    static_assert(offsetof(DevCounters, cnt) == 0, "queue state leads the counter block");
+    HIPCHK(hipMemsetAsync(P.ctr, 0, offsetof(DevCounters, kbase), stream));
     k_fill<<<1, 64, 0, stream>>>(reinterpret_cast<float *>(&P.ctr->lmin[0][0]), (size_t)6, INFINITY);
     last_active = 1;
     iter[0] = iter[1] = 0;
@@ -1556,13 +1649,20 @@ int Engine::fetch_counters() {
 int Engine::wait_published() { return wait_flag(h_flag, pub_seq); }
 int Engine::wait_flag(const unsigned int *flag, unsigned int seq) {
     const auto t0 = std::chrono::steady_clock::now();
+    auto next_query = t0 + std::chrono::milliseconds(200);
     for (unsigned int spins = 1;; ++spins) {
         if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) == seq) return UFM_OK;
         __builtin_ia32_pause();
-        // a faulted kernel never publishes: after 20 s ask the runtime what happened
-        if ((spins & 0xFFFF) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(20)) break;
+        if ((spins & 0xFFF) != 0) continue;
+        // a faulted kernel never publishes: every 200 ms ask the runtime whether the stream is still alive
+        const auto now = std::chrono::steady_clock::now();
+        if (now < next_query) continue;
+        next_query = now + std::chrono::milliseconds(200);
+        const hipError_t q = hipStreamQuery(stream);
+        if (q == hipErrorNotReady) continue;
+        if (q != hipSuccess) return UFM_ERR_HIP_BASE - (int)q;
+        break;                          // the stream has drained: the flag is there by now, or it never will be
     }
-    HIPCHK(hipStreamSynchronize(stream));
     return __atomic_load_n(flag, __ATOMIC_ACQUIRE) == seq ? UFM_OK : UFM_ERR_HIP_BASE;
 }
 
@@ -1574,11 +1674,13 @@ int Engine::relax_kernel(int mode, int k_arg, float rbound, int grid) {
     if (mode == MODE_LOWER) {
         if (algo == UFM_ALGO_FD) UFM_LAUNCH(UFM_ALGO_FD, MODE_LOWER);
         else if (algo == UFM_ALGO_SG) UFM_LAUNCH(UFM_ALGO_SG, MODE_LOWER);
-        else UFM_LAUNCH(UFM_ALGO_DFM, MODE_LOWER);
+        else if (opt_lvl == 0) UFM_LAUNCH(UFM_ALGO_DFM, MODE_LOWER);
+        else UFM_LAUNCH(ALGO_DFM1, MODE_LOWER);
     } else {
         if (algo == UFM_ALGO_FD) UFM_LAUNCH(UFM_ALGO_FD, MODE_RAISE);
         else if (algo == UFM_ALGO_SG) UFM_LAUNCH(UFM_ALGO_SG, MODE_RAISE);
-        else UFM_LAUNCH(UFM_ALGO_DFM, MODE_RAISE);
+        else if (opt_lvl == 0) UFM_LAUNCH(UFM_ALGO_DFM, MODE_RAISE);
+        else UFM_LAUNCH(ALGO_DFM1, MODE_RAISE);
     }
 #undef UFM_LAUNCH
     return UFM_OK;
@@ -1613,6 +1715,7 @@ int Engine::replan_graph(int nr, int nl, float band, hipGraphExec_t *out) {
     hipGraphDestroy(g);
     HIPCHK(err);
     graphs.emplace_back(key, ge);
+    ++graphs_made;
     *out = ge;
     return UFM_OK;
 }
@@ -1646,11 +1749,13 @@ int Engine::launch_relax(int mode, float rbound, hipEvent_t e0, hipEvent_t e1) {
     if (mode == MODE_LOWER) {
         if (algo == UFM_ALGO_FD) UFM_LAUNCH(UFM_ALGO_FD, MODE_LOWER);
         else if (algo == UFM_ALGO_SG) UFM_LAUNCH(UFM_ALGO_SG, MODE_LOWER);
-        else UFM_LAUNCH(UFM_ALGO_DFM, MODE_LOWER);
+        else if (opt_lvl == 0) UFM_LAUNCH(UFM_ALGO_DFM, MODE_LOWER);
+        else UFM_LAUNCH(ALGO_DFM1, MODE_LOWER);
     } else {
         if (algo == UFM_ALGO_FD) UFM_LAUNCH(UFM_ALGO_FD, MODE_RAISE);
         else if (algo == UFM_ALGO_SG) UFM_LAUNCH(UFM_ALGO_SG, MODE_RAISE);
-        else UFM_LAUNCH(UFM_ALGO_DFM, MODE_RAISE);
+        else if (opt_lvl == 0) UFM_LAUNCH(UFM_ALGO_DFM, MODE_RAISE);
+        else UFM_LAUNCH(ALGO_DFM1, MODE_RAISE);
     }
 #undef UFM_LAUNCH
     ++iter[q];
@@ -1673,7 +1778,7 @@ int Engine::run_phase(int mode, float rbound, uint32_t *launches, float *kernel_
     long total = 0;
     if (spin_wait && pipeline_batches && h_pipe_ctr[0]) {
         struct InFlight { unsigned int seq; int slot, ns, iter_after; };
-        constexpr int EVSLOT = 64;                      // events per slot: a batch has at most 32 launches
+        const int EVSLOT = 2 * std::max(32, batch_fixed);   // events per slot: two per launch of a batch (adaptive batches: <= 32 launches)
         while (profiling && ev.size() < (size_t)(4 + 2 * EVSLOT)) { hipEvent_t a; HIPCHK(hipEventCreate(&a)); ev.push_back(a); }
         auto collect = [&](const InFlight &f) -> int {  // wait for the batch, add its timed launches
             int rc = wait_flag(h_pipe_flag[f.slot], f.seq);
@@ -1759,9 +1864,10 @@ int Engine::patch(int m, const uint8_t *dev_patch, int x, int y, int w, int h) {
     if (x < 0 || y < 0 || w <= 0 || h <= 0 || x + h > L || y + w > W) return UFM_ERR_INVALID;   // Graph.cpp:38-41
     const int n = w * h;
     if ((size_t)n > d_pmask_cap) {
-        if (d_pmask) { HIPCHK(hipStreamSynchronize(stream)); hipFree(d_pmask); }
-        d_pmask_cap = n < 4096 ? 4096 : (size_t)n;
-        HIPCHK(hipMalloc(&d_pmask, d_pmask_cap));
+        if (d_pmask) { HIPCHK(hipStreamSynchronize(stream)); hipFree(d_pmask); d_pmask = nullptr; d_pmask_cap = 0; }
+        const size_t cap = n < 4096 ? 4096 : (size_t)n;
+        HIPCHK(hipMalloc(&d_pmask, cap));
+        d_pmask_cap = cap;
     }
     if (n <= 4096) {
         if (algo == UFM_ALGO_DFM) k_patch_small<false><<<1, 1024, 0, stream>>>(P, m, dev_patch, d_pmask, x, y, w, h);
@@ -1791,8 +1897,15 @@ int Engine::step(ufm_stats *out) {
         HIPCHK(hipMemsetAsync(&P.ctr->raise_visits, 0, sizeof(unsigned long long), stream));
         if (profiling) HIPCHK(hipMemsetAsync(P.lmax, 0, sizeof(int) * LMAX, stream));
     }
-    P.focused = focused ? 1 : 0;
-    P.hm = heur ? heuristic_multiplier : 0.0f;
+    // heuristic multiplier / threshold / focused flag live in device memory (DevDyn); a changed value reaches the
+    // device with the first kernel of the step: through the replan graph's job record, or by k_set_dyn
+    const DevDyn dyn_now{heur ? heuristic_multiplier : 0.0f, thr_uchar, focused ? 1 : 0, 0};
+    bool dyn_pending = std::memcmp(&dyn_now, &dyn_dev, sizeof(DevDyn)) != 0;
+    auto flush_dyn = [&]() {
+        if (!dyn_pending) return;
+        k_set_dyn<<<1, 1, 0, stream>>>(P.dyn, dyn_now);
+        dyn_dev = dyn_now; dyn_pending = false;
+    };
 
     // classify maps: (re)initialise, propagate pending patches, or idle  (ReplannerBase.h:48-59)
     int n_init = 0, n_upd = 0;
@@ -1897,6 +2010,7 @@ int Engine::step(ufm_stats *out) {
             int rc = replan_graph(nr, nl, band, &ge);
             if (rc != UFM_OK) return rc;
             h_job->rb = rb; h_job->k_lower = iter[Q_LOWER]; h_job->seq = ++pub_seq;
+            h_job->dyn = dyn_now; dyn_dev = dyn_now; dyn_pending = false;
             __atomic_thread_fence(__ATOMIC_RELEASE);
             HIPCHK(hipGraphLaunch(ge, stream));
             iter[Q_RAISE] += nr; iter[Q_LOWER] += nl;
@@ -1904,6 +2018,7 @@ int Engine::step(ufm_stats *out) {
             rc = wait_published();
             if (rc != UFM_OK) return rc;
         } else {
+        flush_dyn();
         if (fused) {
             rb.k_raise = iter[Q_RAISE]; rb.band = band;
             k_replan_begin<<<1, 1024, 0, stream>>>(P, rb);
@@ -1965,6 +2080,7 @@ int Engine::step(ufm_stats *out) {
             win_pos = (win_pos + 1) % 6;
         }
     } else if (have_seeds) {
+        flush_dyn();
         // num_nodes_updated (FD impl:138, DFM impl:109) of the participating maps
         HIPCHK(hipMemcpyAsync(h_scratch + 2 * nmaps + 2 * nmaps, P.num_updated, sizeof(unsigned int) * nmaps, hipMemcpyDeviceToHost, stream));
         // patches enter an existing field through the invalidation queue, a fresh one directly
@@ -1996,6 +2112,7 @@ int Engine::step(ufm_stats *out) {
     auto t1 = std::chrono::steady_clock::now();
     double u_acc = std::chrono::duration<double, std::milli>(t1 - t0).count(), p_acc = 0.0;
     if (do_plan) {
+        flush_dyn();
         // Invalidate, then lower, both only as far as the start's key (the reference's
         // end_condition).  The invalidation bound must reach the key the start ends up with, which
         // is only known afterwards: start from the current key plus one ordering band and repeat
@@ -2080,6 +2197,7 @@ int Engine::step(ufm_stats *out) {
     st.updated = updated;
     st.queued_lower = (uint32_t)(h_ctr->cnt[Q_LOWER][iter[Q_LOWER] % 3] + h_ctr->npark[Q_LOWER]);   // parked beyond the start's key
     st.queued_raise = (uint32_t)(h_ctr->cnt[Q_RAISE][iter[Q_RAISE] % 3] + h_ctr->npark[Q_RAISE]);
+    st.graphs_instantiated = graphs_made;
     st.u_ms = (float)u_acc;   // seeding + invalidation (the reference's update())
     st.p_ms = (float)p_acc;   // propagation + finalisation (the reference's plan())
     last = st;
@@ -2158,6 +2276,7 @@ int engine_destroy(Engine *e) {
     if (e->d_patch) hipFree(e->d_patch);
     if (e->d_pmask) hipFree(e->d_pmask);
     if (e->d_field) hipFree(e->d_field);
+    if (e->d_info) hipFree(e->d_info);
     if (e->d_jobs) hipFree(e->d_jobs);
     if (e->h_jobs) hipHostFree(e->h_jobs);
     if (e->d_path) hipFree(e->d_path);
@@ -2210,10 +2329,14 @@ int engine_patch(Engine *e, int m, const uint8_t *src, bool on_device, int x, in
     if (w <= 0 || h <= 0) return UFM_ERR_INVALID;
     const size_t n = (size_t)w * h;
     if (n > e->d_patch_cap) {
-        if (e->d_patch) { HIPCHK(hipStreamSynchronize(e->stream)); hipFree(e->d_patch); hipHostFree(e->h_patch); }
-        e->d_patch_cap = n < 4096 ? 4096 : n;
-        HIPCHK(hipMalloc(&e->d_patch, e->d_patch_cap));
-        HIPCHK(hipHostMalloc(&e->h_patch, e->d_patch_cap));
+        if (e->d_patch || e->h_patch) HIPCHK(hipStreamSynchronize(e->stream));
+        if (e->d_patch) hipFree(e->d_patch);
+        if (e->h_patch) hipHostFree(e->h_patch);
+        e->d_patch = nullptr; e->h_patch = nullptr; e->d_patch_cap = 0;   // nothing dangling if an allocation below fails
+        const size_t cap = n < 4096 ? 4096 : n;
+        HIPCHK(hipMalloc(&e->d_patch, cap));
+        HIPCHK(hipHostMalloc(&e->h_patch, cap));
+        e->d_patch_cap = cap;
     } else {
         HIPCHK(hipStreamSynchronize(e->stream));   // staging buffers are reused
     }
@@ -2286,7 +2409,7 @@ int engine_extract_path(Engine *e, int max_steps, int lookahead, int allow_indir
     HIPCHK(hipMemcpyAsync(e->d_jobs, e->h_jobs, sizeof(PathJob) * n, hipMemcpyHostToDevice, e->stream));
     PathField F{};
     F.G = e->P.G; F.cost = e->P.cost;
-    F.EX = e->P.EX; F.EY = e->P.EY; F.L = e->P.L; F.W = e->P.W; F.TY = e->P.TY; F.thr = e->P.thr;
+    F.EX = e->P.EX; F.EY = e->P.EY; F.L = e->P.L; F.W = e->P.W; F.TY = e->P.TY; F.thr = e->thr_uchar;
     F.cells = (e->algo == UFM_ALGO_DFM); F.indirect = allow_indirect != 0;
     k_extract_path<<<n, 64, 0, e->stream>>>(F, e->P.gstride, e->P.cstride, e->d_jobs, e->d_path, ostride,
                                             dev_pts, dev_cst, lookahead != 0, max_steps);
@@ -2317,17 +2440,20 @@ int engine_read_info(Engine *e, int m, int x0, int y0, int nx, int ny, int32_t *
     if (x0 < 0 || y0 < 0 || nx <= 0 || ny <= 0 || x0 + nx > e->P.EX || y0 + ny > e->P.EY) return UFM_ERR_INVALID;
     HIPCHK(hipSetDevice(e->device));
     const size_t n = (size_t)nx * ny;
-    int32_t *d_out = nullptr;
-    HIPCHK(hipMalloc(&d_out, n * 2 * sizeof(int32_t)));
+    if (n * 2 > e->d_info_cap) {        // device buffer kept between calls (a consumer asks window after window)
+        if (e->d_info) { HIPCHK(hipStreamSynchronize(e->stream)); hipFree(e->d_info); e->d_info = nullptr; e->d_info_cap = 0; }
+        HIPCHK(hipMalloc(&e->d_info, n * 2 * sizeof(int32_t)));
+        e->d_info_cap = n * 2;
+    }
+    int32_t *d_out = e->d_info;
     PathField F{};
     F.G = e->P.G + (size_t)m * e->P.gstride; F.cost = e->P.cost + (size_t)m * e->P.cstride;
-    F.EX = e->P.EX; F.EY = e->P.EY; F.L = e->P.L; F.W = e->P.W; F.TY = e->P.TY; F.thr = e->P.thr;
+    F.EX = e->P.EX; F.EY = e->P.EY; F.L = e->P.L; F.W = e->P.W; F.TY = e->P.TY; F.thr = e->thr_uchar;
     F.cells = (e->algo == UFM_ALGO_DFM); F.indirect = (e->algo == UFM_ALGO_FD);   // FD: all five cost cases; SG: B / II / A
     k_info<<<(unsigned)((n + 255) / 256), 256, 0, e->stream>>>(F, e->opt_lvl, x0, y0, nx, ny, d_out);
     hipError_t err = hipGetLastError();
     if (err == hipSuccess) err = hipMemcpyAsync(info, d_out, n * 2 * sizeof(int32_t), hipMemcpyDeviceToHost, e->stream);
     if (err == hipSuccess) err = hipStreamSynchronize(e->stream);
-    hipFree(d_out);
     HIPCHK(err);
     return UFM_OK;
 }
@@ -2336,7 +2462,7 @@ int engine_read_info(Engine *e, int m, int x0, int y0, int nx, int ny, int32_t *
 
 // ---- C ABI ---------------------------------------------------------------------------
 struct ufm_planner { Engine *e; };
-struct ufm_batch { Engine *e; };
+struct ufm_batch { std::vector<Engine *> shards; int n_maps = 0, per = 1; };
 
 extern "C" {
 
@@ -2385,7 +2511,6 @@ int ufm_reset(ufm_t *p) { if (!p) return UFM_ERR_INVALID; p->e->maps[0].initiali
 int ufm_set_occupancy_threshold(ufm_t *p, float thr) {
     if (!p) return UFM_ERR_INVALID;
     p->e->thr_uchar = (int)(thr * 255.0f);   // Graph.cpp:18-20
-    p->e->P.thr = p->e->thr_uchar;
     return UFM_OK;
 }
 int ufm_set_heuristic_multiplier(ufm_t *p, float mult) { if (!p) return UFM_ERR_INVALID; p->e->heuristic_multiplier = mult; return UFM_OK; }
@@ -2427,21 +2552,34 @@ static int engine_check_layout(Engine *e, uint64_t *bad_ring, uint64_t *bad_cost
     return UFM_OK;
 }
 int ufm_check_layout(ufm_t *p, uint64_t *bad_ring, uint64_t *bad_cost) { return p ? engine_check_layout(p->e, bad_ring, bad_cost) : UFM_ERR_INVALID; }
-int ufm_batch_check_layout(ufm_batch_t *b, uint64_t *bad_ring, uint64_t *bad_cost) { return b ? engine_check_layout(b->e, bad_ring, bad_cost) : UFM_ERR_INVALID; }
-int ufm_read_map(ufm_t *p, uint8_t *host_map) {
-    if (!p || !host_map || !p->e->allocated) return UFM_ERR_INVALID;
-    HIPCHK(hipSetDevice(p->e->device));
-    HIPCHK(hipMemcpyAsync(host_map, p->e->P.cost, p->e->P.cstride, hipMemcpyDeviceToHost, p->e->stream));
-    HIPCHK(hipStreamSynchronize(p->e->stream));
+int ufm_batch_check_layout(ufm_batch_t *b, uint64_t *bad_ring, uint64_t *bad_cost) {
+    if (!b) return UFM_ERR_INVALID;
+    uint64_t r = 0, c = 0;
+    for (Engine *e : b->shards) {
+        uint64_t a = 0, d = 0;
+        const int rc = engine_check_layout(e, &a, &d);
+        if (rc != UFM_OK) return rc;
+        r += a; c += d;
+    }
+    if (bad_ring) *bad_ring = r;
+    if (bad_cost) *bad_cost = c;
     return UFM_OK;
 }
+static int engine_read_map(Engine *e, int m, uint8_t *host_map) {
+    if (!e || !host_map || !e->allocated || m < 0 || m >= e->nmaps) return UFM_ERR_INVALID;
+    HIPCHK(hipSetDevice(e->device));
+    HIPCHK(hipMemcpyAsync(host_map, e->P.cost + (size_t)m * e->P.cstride, e->P.cstride, hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    return UFM_OK;
+}
+int ufm_read_map(ufm_t *p, uint8_t *host_map) { return p ? engine_read_map(p->e, 0, host_map) : UFM_ERR_INVALID; }
 static int engine_set_param(Engine *e, const char *name, double value) {
     if (!e || !name) return UFM_ERR_INVALID;
     if (!std::strcmp(name, "delta")) e->delta_abs = (float)value;
     else if (!std::strcmp(name, "delta_scale")) { e->delta_scale = e->delta_scale_long = (float)value; e->delta_abs = -1.0f; }
     else if (!std::strcmp(name, "delta_scale_long")) { e->delta_scale_long = (float)value; e->delta_abs = -1.0f; }
     else if (!std::strcmp(name, "max_iters")) e->max_iters = value < 1 ? 1 : (int)value;
-    else if (!std::strcmp(name, "batch")) e->batch_fixed = (int)value;
+    else if (!std::strcmp(name, "batch")) e->batch_fixed = value < 0 ? 0 : (value > 1024 ? 1024 : (int)value);
     else if (!std::strcmp(name, "pipeline_batches")) e->pipeline_batches = value != 0;
     else if (!std::strcmp(name, "grid")) e->grid_relax = value < 1 ? 1 : (int)value;
     else if (!std::strcmp(name, "small_grid")) e->small_grid = value < 1 ? 1 : (int)value;
@@ -2459,51 +2597,120 @@ static int engine_set_param(Engine *e, const char *name, double value) {
     return UFM_OK;
 }
 int ufm_set_param(ufm_t *p, const char *name, double value) { return p ? engine_set_param(p->e, name, value) : UFM_ERR_INVALID; }
-int ufm_batch_set_param(ufm_batch_t *b, const char *name, double value) { return b ? engine_set_param(b->e, name, value) : UFM_ERR_INVALID; }
+int ufm_batch_set_param(ufm_batch_t *b, const char *name, double value) {
+    if (!b) return UFM_ERR_INVALID;
+    for (Engine *e : b->shards) { const int rc = engine_set_param(e, name, value); if (rc != UFM_OK) return rc; }
+    return UFM_OK;
+}
 int ufm_set_profiling(ufm_t *p, int enable) { if (!p) return UFM_ERR_INVALID; p->e->profiling = enable != 0; return UFM_OK; }
 void *ufm_stream(ufm_t *p) { return p ? (void *)p->e->stream : nullptr; }
 
-int ufm_batch_create(ufm_batch_t **out, int n_maps, int algo, int opt_lvl, int use_heuristic, int device_id) {
-    if (!out) return UFM_ERR_INVALID;
-    Engine *e = nullptr;
-    int rc = engine_create(&e, n_maps, algo, opt_lvl, use_heuristic, device_id);
-    if (rc != UFM_OK) return rc;
-    *out = new ufm_batch{e};
+// A batch is one engine per device; map i lives in shard i / per (contiguous blocks of maps).
+static int batch_locate(const ufm_batch *b, int i, Engine **e, int *local) {
+    if (!b || i < 0 || i >= b->n_maps) return UFM_ERR_INVALID;
+    const int s = i / b->per;
+    *e = b->shards[s];
+    *local = i - s * b->per;
     return UFM_OK;
+}
+int ufm_batch_create_sharded(ufm_batch_t **out, int n_maps, int algo, int opt_lvl, int use_heuristic, const int *devices, int n_devices) {
+    if (!out || !devices || n_devices < 1 || n_maps < n_devices) return UFM_ERR_INVALID;
+    ufm_batch *b = new (std::nothrow) ufm_batch();
+    if (!b) return UFM_ERR_NOMEM;
+    b->n_maps = n_maps;
+    b->per = (n_maps + n_devices - 1) / n_devices;
+    for (int s = 0; s * b->per < n_maps; ++s) {
+        Engine *e = nullptr;
+        const int cnt = std::min(b->per, n_maps - s * b->per);
+        const int rc = engine_create(&e, cnt, algo, opt_lvl, use_heuristic, devices[s]);
+        if (rc != UFM_OK) { ufm_batch_destroy(b); return rc; }
+        b->shards.push_back(e);
+    }
+    *out = b;
+    return UFM_OK;
+}
+int ufm_batch_create(ufm_batch_t **out, int n_maps, int algo, int opt_lvl, int use_heuristic, int device_id) {
+    return ufm_batch_create_sharded(out, n_maps, algo, opt_lvl, use_heuristic, &device_id, 1);
 }
 int ufm_batch_destroy(ufm_batch_t *b) {
     if (!b) return UFM_ERR_INVALID;
-    int rc = engine_destroy(b->e);
+    int rc = UFM_OK;
+    for (Engine *e : b->shards) { const int r = engine_destroy(e); if (rc == UFM_OK) rc = r; }
     delete b;
     return rc;
 }
-int ufm_batch_size(const ufm_batch_t *b) { return b ? b->e->nmaps : UFM_ERR_INVALID; }
+int ufm_batch_size(const ufm_batch_t *b) { return b ? b->n_maps : UFM_ERR_INVALID; }
+int ufm_batch_shards(const ufm_batch_t *b) { return b ? (int)b->shards.size() : UFM_ERR_INVALID; }
 int ufm_batch_set_occupancy_threshold(ufm_batch_t *b, float thr) {
     if (!b) return UFM_ERR_INVALID;
-    b->e->thr_uchar = (int)(thr * 255.0f);
-    b->e->P.thr = b->e->thr_uchar;
+    for (Engine *e : b->shards) e->thr_uchar = (int)(thr * 255.0f);
     return UFM_OK;
 }
-int ufm_batch_set_map(ufm_batch_t *b, int i, const uint8_t *host_map, int width, int length) { return b ? engine_set_map(b->e, i, host_map, false, width, length) : UFM_ERR_INVALID; }
-int ufm_batch_patch_map(ufm_batch_t *b, int i, const uint8_t *host_patch, int x, int y, int w, int h) { return b ? engine_patch(b->e, i, host_patch, false, x, y, w, h) : UFM_ERR_INVALID; }
+int ufm_batch_set_heuristic_multiplier(ufm_batch_t *b, float mult) {
+    if (!b) return UFM_ERR_INVALID;
+    for (Engine *e : b->shards) e->heuristic_multiplier = mult;
+    return UFM_OK;
+}
+#define UFM_BATCH_MAP(b, i) Engine *e = nullptr; int li = 0; { const int rc_ = batch_locate(b, i, &e, &li); if (rc_ != UFM_OK) return rc_; }
+int ufm_batch_set_map(ufm_batch_t *b, int i, const uint8_t *host_map, int width, int length) { UFM_BATCH_MAP(b, i); return engine_set_map(e, li, host_map, false, width, length); }
+int ufm_batch_set_map_device(ufm_batch_t *b, int i, const uint8_t *dev_map, int width, int length) { UFM_BATCH_MAP(b, i); return engine_set_map(e, li, dev_map, true, width, length); }
+int ufm_batch_patch_map(ufm_batch_t *b, int i, const uint8_t *host_patch, int x, int y, int w, int h) { UFM_BATCH_MAP(b, i); return engine_patch(e, li, host_patch, false, x, y, w, h); }
+int ufm_batch_patch_map_device(ufm_batch_t *b, int i, const uint8_t *dev_patch, int x, int y, int w, int h) { UFM_BATCH_MAP(b, i); return engine_patch(e, li, dev_patch, true, x, y, w, h); }
 int ufm_batch_set_start(ufm_batch_t *b, int i, float x, float y) {
-    if (!b || i < 0 || i >= b->e->nmaps) return UFM_ERR_INVALID;
-    MapState &ms = b->e->maps[i];
+    UFM_BATCH_MAP(b, i);
+    MapState &ms = e->maps[li];
     ms.start_x = x; ms.start_y = y; ms.new_start = true; ms.start_set = true;
     return UFM_OK;
 }
-int ufm_batch_set_goal(ufm_batch_t *b, int i, float x, float y) { return b ? engine_set_goal(b->e, i, x, y) : UFM_ERR_INVALID; }
+int ufm_batch_set_goal(ufm_batch_t *b, int i, float x, float y) { UFM_BATCH_MAP(b, i); return engine_set_goal(e, li, x, y); }
 int ufm_batch_reset(ufm_batch_t *b, int i) {
-    if (!b || i < 0 || i >= b->e->nmaps) return UFM_ERR_INVALID;
-    b->e->maps[i].initialize_search = true;
+    UFM_BATCH_MAP(b, i);
+    e->maps[li].initialize_search = true;
     return UFM_OK;
 }
+// One step of every map.  Shards on different devices advance side by side, one host thread each (a step is
+// synchronous: its host thread spins on the device's published counters); the statistics are summed, the times
+// are those of the slowest shard.
 int ufm_batch_step(ufm_batch_t *b, ufm_stats *stats) {
-    if (!b) return UFM_ERR_INVALID;
-    if (hipSetDevice(b->e->device) != hipSuccess) return UFM_ERR_HIP_BASE;
-    return b->e->step(stats);
+    if (!b || b->shards.empty()) return UFM_ERR_INVALID;
+    const size_t n = b->shards.size();
+    std::vector<ufm_stats> st(n);
+    std::vector<int> rcs(n, UFM_OK);
+    auto run = [&](size_t s) {
+        if (hipSetDevice(b->shards[s]->device) != hipSuccess) { rcs[s] = UFM_ERR_HIP_BASE; return; }
+        rcs[s] = b->shards[s]->step(&st[s]);
+    };
+    if (n == 1) run(0);
+    else {
+        std::vector<std::thread> th;
+        for (size_t s = 1; s < n; ++s) th.emplace_back(run, s);
+        run(0);
+        for (auto &t : th) t.join();
+    }
+    for (size_t s = 0; s < n; ++s) if (rcs[s] != UFM_OK) return rcs[s];
+    if (stats) {
+        ufm_stats a = st[0];
+        for (size_t s = 1; s < n; ++s) {
+            const ufm_stats &c = st[s];
+            a.u_ms = std::max(a.u_ms, c.u_ms); a.p_ms = std::max(a.p_ms, c.p_ms);
+            a.updated += c.updated; a.expanded += c.expanded; a.tile_visits += c.tile_visits; a.tile_iters += c.tile_iters;
+            a.elem_evals += c.elem_evals; a.launches += c.launches; a.raise_launches += c.raise_launches; a.kernel_ms += c.kernel_ms;
+            a.crit_sweeps += c.crit_sweeps; a.raise_tile_visits += c.raise_tile_visits; a.raise_kernel_ms += c.raise_kernel_ms;
+            a.queued_lower += c.queued_lower; a.queued_raise += c.queued_raise; a.timed_launches += c.timed_launches;
+            a.timed_raise_launches += c.timed_raise_launches; a.graphs_instantiated += c.graphs_instantiated;
+        }
+        *stats = a;
+    }
+    return UFM_OK;
 }
-int ufm_batch_read_field(ufm_batch_t *b, int i, int x0, int y0, int nx, int ny, float *g, float *rhs) { return b ? engine_read_field(b->e, i, x0, y0, nx, ny, g, rhs) : UFM_ERR_INVALID; }
+int ufm_batch_read_field(ufm_batch_t *b, int i, int x0, int y0, int nx, int ny, float *g, float *rhs) { UFM_BATCH_MAP(b, i); return engine_read_field(e, li, x0, y0, nx, ny, g, rhs); }
+int ufm_batch_read_map(ufm_batch_t *b, int i, uint8_t *host_map) { UFM_BATCH_MAP(b, i); return engine_read_map(e, li, host_map); }
+int ufm_batch_set_profiling(ufm_batch_t *b, int enable) {
+    if (!b) return UFM_ERR_INVALID;
+    for (Engine *e : b->shards) e->profiling = enable != 0;
+    return UFM_OK;
+}
+void *ufm_batch_stream(ufm_batch_t *b, int shard) { return (b && shard >= 0 && shard < (int)b->shards.size()) ? (void *)b->shards[shard]->stream : nullptr; }
 
 int ufm_read_info(ufm_t *p, int x0, int y0, int nx, int ny, int32_t *info) { return p ? engine_read_info(p->e, 0, x0, y0, nx, ny, info) : UFM_ERR_INVALID; }
 int ufm_extract_path(ufm_t *p, int max_steps, int lookahead, int allow_indirect,
@@ -2512,7 +2719,16 @@ int ufm_extract_path(ufm_t *p, int max_steps, int lookahead, int allow_indirect,
 }
 int ufm_batch_extract_path(ufm_batch_t *b, int max_steps, int lookahead, int allow_indirect,
                            float *path_xy, int cap_points, float *step_costs, int cap_costs, ufm_path_info *info) {
-    return b ? engine_extract_path(b->e, max_steps, lookahead, allow_indirect, path_xy, cap_points, step_costs, cap_costs, info) : UFM_ERR_INVALID;
+    if (!b) return UFM_ERR_INVALID;
+    int first = 0;                      // shard by shard (one launch each), outputs in map order
+    for (Engine *e : b->shards) {
+        const int rc = engine_extract_path(e, max_steps, lookahead, allow_indirect,
+                                           path_xy ? path_xy + (size_t)first * cap_points * 2 : nullptr, cap_points,
+                                           step_costs ? step_costs + (size_t)first * cap_costs : nullptr, cap_costs, info ? info + first : nullptr);
+        if (rc != UFM_OK) return rc;
+        first += e->nmaps;
+    }
+    return UFM_OK;
 }
 
 }  // extern "C"

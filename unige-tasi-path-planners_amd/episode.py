@@ -102,3 +102,99 @@ def timed_episodes(run_one, steps, warmup, barrier):
     out = [run_one() for _ in range(steps)]
     barrier()
     return time.perf_counter() - t0, out
+
+
+# ---- batch form (BASELINE config 4): M independent maps per rank, every map with a patch stream of its own ----
+REC_HDR = 16    # bytes: int32 map id (global), top, left, patch edge
+
+
+def pack_round(entries, psz):
+    """One replan round of the whole job as the byte records rank 0 broadcasts: per global map one record
+    {int32 map_id, top, left, edge; uint8 patch[edge][edge]}, padded to a multiple of 16 bytes.
+    entries: list of (map_id, top, left, patch ndarray).  Returns a uint8 ndarray [n][rec]."""
+    import numpy as np
+    rec = (REC_HDR + psz * psz + 15) // 16 * 16
+    out = np.zeros((len(entries), rec), np.uint8)
+    for i, (g, top, left, patch) in enumerate(entries):
+        out[i, :REC_HDR] = np.array([g, top, left, psz], np.int32).view(np.uint8)
+        out[i, REC_HDR:REC_HDR + psz * psz] = patch.reshape(-1)
+    return out
+
+
+class RoundStream:
+    """Rank 0 owns the patch streams of ALL maps of the job; per replan round it broadcasts one packed buffer
+    (pack_round) and every rank takes the records of its own maps out of it.  `rounds` (rank 0): tensor
+    [n_rounds][n_global_maps][rec]; `recv`: one or two tensors [n_global_maps][rec] on the other ranks.
+    With pipeline=True (two receive buffers) round i+1 travels while the maps replan round i."""
+
+    def __init__(self, rounds, recv, n_rounds, dist=None, rank=0, pipeline=False):
+        self.rounds = None if rounds is None else [rounds[i] for i in range(n_rounds)]
+        self.recv = list(recv) if isinstance(recv, (list, tuple)) else [recv]
+        self.dist, self.rank, self.count = dist, rank, n_rounds
+        self.pipeline = bool(pipeline) and dist is not None and len(self.recv) >= 2
+        self.broadcasts = 0
+        self._inflight = {}
+
+    def _buffer(self, i):
+        return self.rounds[i] if self.rank == 0 else self.recv[i % len(self.recv)]
+
+    def _issue(self, i):
+        buf = self._buffer(i)
+        self._inflight[i] = (self.dist.broadcast(buf, src=0, async_op=True), buf)
+
+    def close(self):
+        for work, _ in self._inflight.values():
+            work.wait()
+        self._inflight.clear()
+
+    def fetch(self, i):
+        if self.dist is None:
+            return self.rounds[i]
+        if not self.pipeline:
+            buf = self._buffer(i)
+            self.dist.broadcast(buf, src=0)
+            self.broadcasts += 1
+            return buf
+        if i not in self._inflight:
+            self._issue(i)
+        work, buf = self._inflight.pop(i)
+        work.wait()
+        self.broadcasts += 1
+        if i + 1 < self.count:
+            self._issue(i + 1)
+        return buf
+
+
+def run_batch_episode(batch, n_maps, first_map, set_maps, start, goal, starts, stream, headers_of, apply_record, read_stats):
+    """Full plan of the rank's n_maps maps (global ids first_map ..), then one batch step per replan round.
+    starts[i]: the start position of round i; headers_of(buf) -> int32 ndarray [n_global][4] (host copy of the
+    record headers); apply_record(batch, local_map, buf, global_map, top, left, edge)."""
+    tot = {}
+
+    def acc():
+        for k, v in read_stats(batch).items():
+            tot[k] = tot.get(k, 0) + v
+
+    set_maps(batch)
+    for m in range(n_maps):
+        batch.reset(m)
+        batch.set_start(m, *start)
+        batch.set_goal(m, *goal)
+    rc = batch.step()
+    if rc != 0:
+        raise RuntimeError("batch plan step failed: %d" % rc)
+    acc()
+    for i in range(stream.count):
+        buf = stream.fetch(i)
+        hdr = headers_of(buf)
+        for m in range(n_maps):
+            g, top, left, edge = (int(v) for v in hdr[first_map + m])
+            if g != first_map + m:
+                raise RuntimeError("round %d: record %d carries map id %d" % (i, first_map + m, g))
+            apply_record(batch, m, buf, first_map + m, top, left, edge)
+            batch.set_start(m, *starts[i])
+        rc = batch.step()
+        if rc != 0:
+            raise RuntimeError("batch replan round %d failed: %d" % (i, rc))
+        acc()
+    return tot
