@@ -61,6 +61,8 @@ typedef struct ufm_stats {
     uint32_t timed_raise_launches; /*   every launch of a replan); of which in the invalidation phase (raise_kernel_ms) */
     uint32_t graphs_instantiated;  /* cumulative: replan submissions captured and instantiated as hipGraphs by this handle (a
                                     * new heuristic multiplier / threshold must not add one: they travel through memory) */
+    uint32_t region_replans;       /* cumulative: replans submitted to the block-resident kernel (one workgroup, both phases in LDS) */
+    uint32_t region_replans_done;  /*   ... and completed by it alone (the others were finished by the launch chain) */
     uint32_t reserved0;
 } ufm_stats;
 
@@ -112,7 +114,9 @@ int ufm_check_layout(ufm_t *p, uint64_t *bad_ring_entries, uint64_t *bad_cost_by
  * (0: adaptive); "grid": workgroups per relax launch.
  * "focused" (default 1): honour the reference's end_condition -- propagate only as far as the
  * start's key and keep the rest queued for later steps, like the reference's priority queue;
- * 0 converges the whole field every step (every element then holds its final value). ---- */
+ * 0 converges the whole field every step (every element then holds its final value).
+ * "region" (default 1): replans run in one workgroup on an LDS-resident block of tiles around the patch
+ * ("region_tiles" per side, goal-side edge "region_ahead" tiles beyond the patch centre); 0: launch chain only. ---- */
 int ufm_set_param(ufm_t *p, const char *name, double value);
 
 /* ---- back-pointers: the `Info` member of a level-1/2 map element (ExpandedMap.h:27-29; set in

@@ -72,3 +72,27 @@ def check_parity(o, g, what="", below_start_key=False):
     # the engine's redundant copies (neighbour rings, cost windows) agree with their originals
     assert g.check_layout() == (0, 0), "%s: layout self-check %r" % (what, g.check_layout())
     return n, nbad
+
+
+class DeviceBytes:
+    """A buffer in HBM filled from a numpy array, through the HIP runtime directly (ctypes on libamdhip64): for the
+    tests of the *_device entry points, which take plain device pointers."""
+    _hip = None
+
+    def __init__(self, arr):
+        import ctypes as C
+        if DeviceBytes._hip is None:
+            DeviceBytes._hip = C.CDLL("libamdhip64.so")
+        hip = DeviceBytes._hip
+        arr = np.ascontiguousarray(arr)
+        self.ptr = C.c_void_p()
+        assert hip.hipMalloc(C.byref(self.ptr), C.c_size_t(max(1, arr.nbytes))) == 0
+        assert hip.hipMemcpy(self.ptr, C.c_void_p(arr.ctypes.data), C.c_size_t(arr.nbytes), 1) == 0     # hipMemcpyHostToDevice, synchronous
+
+    def data_ptr(self):
+        return self.ptr.value
+
+    def free(self):
+        if self.ptr:
+            DeviceBytes._hip.hipFree(self.ptr)
+            self.ptr = None

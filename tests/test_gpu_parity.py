@@ -4,7 +4,7 @@ import pytest
 
 import ufm_amd
 import oracle_py as orc
-from helpers import ALGOS, DFM_RTOL, check_parity, make_pair
+from helpers import ALGOS, DFM_RTOL, DeviceBytes, check_parity, make_pair
 
 pytestmark = pytest.mark.gpu
 
@@ -345,8 +345,9 @@ def test_patches_accumulate_until_the_next_step():
 
 @pytest.mark.parametrize("algo,lvl", [("FD", 1), ("DFM", 1)])
 def test_replan_submission_variants_agree(algo, lvl):
-    """A replan is submitted as one captured graph of fused control kernels whose result the host
-    picks up from host-coherent memory.  Each of the three mechanisms can be switched off; fields
+    """A replan runs in the block-resident kernel (one workgroup, both phases in LDS) and falls back to the
+    launch chain -- one captured graph of fused control kernels whose result the host picks up from
+    host-coherent memory.  Each of the mechanisms can be switched off; fields
     (focused mode, below the start key: against the oracle; full field: bitwise between variants in
     full-field mode), num_nodes_updated and num_nodes_expanded must not depend on them.  Includes a
     step with 6 pending patches (more than the fused kernel takes) and one with a 70x70 patch
@@ -358,7 +359,9 @@ def test_replan_submission_variants_agree(algo, lvl):
     script = list(ufm_amd.synth.replan_script(seed, width, length, n_patches=12))
     rng = np.random.default_rng(3)
     big = rng.integers(1, 200, (70, 70), dtype=np.uint8)
-    variants = [dict(), dict(graph=0), dict(graph=0, fuse_control=0), dict(graph=0, fuse_control=0, spin_wait=0), dict(spin_wait=0)]
+    # default: the block-resident kernel (region); region=0: the launch chain in its submission forms
+    variants = [dict(), dict(region_tiles=3, region_band=0), dict(region=0), dict(region=0, graph=0), dict(region=0, graph=0, fuse_control=0),
+                dict(region=0, graph=0, fuse_control=0, spin_wait=0), dict(region=0, spin_wait=0)]
     results = []
     for full in (1, 0):
         results.clear()
@@ -712,7 +715,6 @@ def test_batch_device_inputs_and_sharded_handle():
     filled) and ufm_batch_create_sharded (here: two engines on the one device of the box, devices = [0, 0]; on a
     node each shard gets its own GPU and ufm_batch_step advances them side by side) give the fields of a
     one-engine batch fed from host memory, bit for bit (FD, full-field mode)."""
-    import torch
     n, size = 4, 160
     costs = [ufm_amd.synth.cost_map(50 + i, size, size) for i in range(n)]
     start, goal = ufm_amd.synth.start_goal(size, size)
@@ -720,22 +722,20 @@ def test_batch_device_inputs_and_sharded_handle():
     a = ufm_amd.BatchPlanner(n, ufm_amd.ALGO_FD, 1)
     b = ufm_amd.BatchPlanner(n, ufm_amd.ALGO_FD, 1, devices=[0, 0])
     assert b.shards() == 2 and a.shards() == 1
-    d_costs = [torch.from_numpy(c).cuda() for c in costs]
+    d_costs = [DeviceBytes(c) for c in costs]
     for p in (a, b):
         p.set_param("focused", 0); p.set_occupancy_threshold(1)
     for i in range(n):
         a.set_map(i, costs[i]); b.set_map_device(i, d_costs[i].data_ptr(), size, size)
         for p in (a, b):
             p.set_start(i, *start); p.set_goal(i, *goal)
-    torch.cuda.synchronize()
     assert a.step() == 0 and b.step() == 0
     assert b.stats.expanded == a.stats.expanded
     for r in range(3):
         keep = []
         for i in range(n):
             k, s, top, left, patch = scripts[i][r]
-            dp = torch.from_numpy(patch.copy()).cuda(); keep.append(dp)
-            torch.cuda.synchronize()
+            dp = DeviceBytes(patch); keep.append(dp)
             a.patch_map(i, patch, top, left); b.patch_map_device(i, dp.data_ptr(), top, left, 31, 31)
             for p in (a, b):
                 p.set_start(i, *s)
@@ -749,3 +749,5 @@ def test_batch_device_inputs_and_sharded_handle():
     for x, y in zip(pa, pb):
         assert np.array_equal(x[0], y[0]) and x[2] == y[2]
     a.close(); b.close()
+    for d in d_costs:
+        d.free()

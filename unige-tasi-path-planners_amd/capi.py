@@ -46,6 +46,8 @@ class Stats(C.Structure):
         ("timed_launches", C.c_uint32),
         ("timed_raise_launches", C.c_uint32),
         ("graphs_instantiated", C.c_uint32),
+        ("region_replans", C.c_uint32),
+        ("region_replans_done", C.c_uint32),
         ("reserved0", C.c_uint32),
     ]
 

@@ -24,6 +24,7 @@
 #include <hip/hip_ext.h>
 
 #include <chrono>
+#include <climits>
 #include <cmath>
 #include <cstddef>
 #include <cstdio>
@@ -377,41 +378,48 @@ __device__ __forceinline__ float q_dfm(float a, float b, float th) {
 // quarter of the one-lane-per-node form.  Cell q of node (x,y): (x-1+dx, y-1+dy), dx=q>>1, dy=q&1;
 // its triangles: (p1 = vertical neighbour, p2 = diagonal) and (p1 = horizontal neighbour, p2).
 template <int ALGO> struct QuadConsts;
+// load_at: `cost(r, c)` returns the traversal cost (float, +inf = obstacle / outside) of entry (r, c) of the staged
+// cost window -- row r, column c <-> cell (x0 + r - off, y0 + c - off), off = 1 for node planners; (lx, ly) is the
+// element inside the staged block.  load(): the tile kernel's float window Cs with pitch CP.
 template <> struct QuadConsts<UFM_ALGO_DFM> {
     float th;   // lane 0: cost (orthogonal stencil, h = 1); lane 1: cost*SQRT2 (diagonal stencil)
-    __device__ __forceinline__ void load(const float *Cs, int lx, int ly, int q) {
-        const float tau = Cs[lx * CP + ly];
+    template <class CostAt> __device__ __forceinline__ void load_at(CostAt cost, int lx, int ly, int q, int /*gpitch*/) {
+        const float tau = cost(lx, ly);
         th = (q & 1) ? tau * SQRT2F : tau;
     }
+    __device__ __forceinline__ void load(const float *Cs, int lx, int ly, int q) { load_at([=](int r, int c) { return Cs[r * CP + c]; }, lx, ly, q, GP); }
 };
 template <> struct QuadConsts<ALGO_DFM1> {
     float th;   // lanes 0, 1: cost (h = 1); lanes 2, 3: cost*SQRT2 (= cost * HYPOT(+-1, +-1))
     int so, po; // LDS offsets: +-so = the lane's two neighbours, +-po = the perpendicular pair of the same stencil
-    __device__ __forceinline__ void load(const float *Cs, int lx, int ly, int q) {
-        const float tau = Cs[lx * CP + ly];
+    template <class CostAt> __device__ __forceinline__ void load_at(CostAt cost, int lx, int ly, int q, int gpitch) {
+        const float tau = cost(lx, ly);
         th = (q & 2) ? tau * SQRT2F : tau;
-        so = (q == 0) ? GP : (q == 1) ? 1 : (q == 2) ? GP - 1 : GP + 1;   // vertical | horizontal | TR-BL | TL-BR
-        po = (q == 0) ? 1 : (q == 1) ? GP : (q == 2) ? GP + 1 : GP - 1;   // (dx != dy -> TL/BR pair, dx == dy -> BL/TR pair, impl:284-296)
+        so = (q == 0) ? gpitch : (q == 1) ? 1 : (q == 2) ? gpitch - 1 : gpitch + 1;   // vertical | horizontal | TR-BL | TL-BR
+        po = (q == 0) ? 1 : (q == 1) ? gpitch : (q == 2) ? gpitch + 1 : gpitch - 1;   // (dx != dy -> TL/BR pair, dx == dy -> BL/TR pair, impl:284-296)
     }
+    __device__ __forceinline__ void load(const float *Cs, int lx, int ly, int q) { load_at([=](int r, int c) { return Cs[r * CP + c]; }, lx, ly, q, GP); }
 };
 template <> struct QuadConsts<UFM_ALGO_SG> {
     CellSG k;
-    __device__ __forceinline__ void load(const float *Cs, int lx, int ly, int q) {
-        k.set(Cs[(lx + (q >> 1)) * CP + ly + (q & 1)]);
+    template <class CostAt> __device__ __forceinline__ void load_at(CostAt cost, int lx, int ly, int q, int /*gpitch*/) {
+        k.set(cost(lx + (q >> 1), ly + (q & 1)));
     }
+    __device__ __forceinline__ void load(const float *Cs, int lx, int ly, int q) { load_at([=](int r, int c) { return Cs[r * CP + c]; }, lx, ly, q, GP); }
 };
 template <> struct QuadConsts<UFM_ALGO_FD> {
     CellFD k;
     TriFD tv, th;   // b = the cell across the edge s-p1 (FieldDPlanner_impl.h:322-337)
-    __device__ __forceinline__ void load(const float *Cs, int lx, int ly, int q) {
+    template <class CostAt> __device__ __forceinline__ void load_at(CostAt cost, int lx, int ly, int q, int /*gpitch*/) {
         const int dx = q >> 1, dy = q & 1;
-        const float c = Cs[(lx + dx) * CP + ly + dy];
-        const float bv = Cs[(lx + dx) * CP + ly + 1 - dy];   // across the vertical edge s-p1
-        const float bh = Cs[(lx + 1 - dx) * CP + ly + dy];   // across the horizontal edge s-p1
+        const float c = cost(lx + dx, ly + dy);
+        const float bv = cost(lx + dx, ly + 1 - dy);   // across the vertical edge s-p1
+        const float bh = cost(lx + 1 - dx, ly + dy);   // across the horizontal edge s-p1
         k = {c, c * c, c * SQRT2F};
         tv.set(c, bv);
         th.set(c, bh);
     }
+    __device__ __forceinline__ void load(const float *Cs, int lx, int ly, int q) { load_at([=](int r, int c) { return Cs[r * CP + c]; }, lx, ly, q, GP); }
 };
 
 __device__ __forceinline__ float quad_min(float v) {
@@ -435,14 +443,14 @@ __device__ __forceinline__ float quad_min(float v) {
 }
 
 // ctr points at the node inside the LDS tile; returns this lane's share of RHS(node)
-template <int ALGO>
+template <int ALGO, int GPITCH = GP>
 __device__ __forceinline__ float eval_quad(const float *ctr, int q, const QuadConsts<ALGO> &C) {
     if constexpr (ALGO == UFM_ALGO_DFM) {
         // DynamicFastMarching_impl.h:157-210: best_cell (:344-351) is a min on values, and
         // "diag < ortho ? diag : ortho" is the quad min of the two stencil solves
         float r = INFINITY;
         if (q < 2) {
-            const int a = q ? -GP - 1 : -GP, b = q ? GP + 1 : GP, c = q ? GP - 1 : -1, d = q ? -GP + 1 : 1;
+            const int a = q ? -GPITCH - 1 : -GPITCH, b = q ? GPITCH + 1 : GPITCH, c = q ? GPITCH - 1 : -1, d = q ? -GPITCH + 1 : 1;
             r = q_dfm(fminf(ctr[a], ctr[b]), fminf(ctr[c], ctr[d]), C.th);
         }
         return r;
@@ -452,7 +460,7 @@ __device__ __forceinline__ float eval_quad(const float *ctr, int q, const QuadCo
         const float pm = fminf(ctr[-C.po], ctr[C.po]);
         return fminf(q_dfm(ctr[-C.so], pm, C.th), q_dfm(ctr[C.so], pm, C.th));
     } else {
-        const int sx = (q & 2) ? GP : -GP, sy = (q & 1) ? 1 : -1;
+        const int sx = (q & 2) ? GPITCH : -GPITCH, sy = (q & 1) ? 1 : -1;
         const float gD = ctr[sx + sy], gV = ctr[sx], gH = ctr[sy];
         if constexpr (ALGO == UFM_ALGO_SG)   // ShiftedGridPlanner_impl.h:258-264
             return fminf(tri_sg(gV, gD, C.k), tri_sg(gH, gD, C.k));
@@ -1391,6 +1399,8 @@ __global__ __launch_bounds__(1024) void k_raise_to_lower(DevParams P, int k_lowe
     unpark(P, Q_LOWER, k_lower, INFINITY, s_keep);
 }
 
+#include "ufm_region.h"
+
 // ---- host side -------------------------------------------------------------------
 #define HIPCHK(expr)                                                      \
     do {                                                                  \
@@ -1433,6 +1443,14 @@ struct Engine {
     bool spin_wait = true;           // false: hipMemcpyAsync + hipStreamSynchronize instead
     bool fuse_control = true;        // replans: fused control kernels (k_replan_begin / _raise_to_lower / _end)
     bool use_graph = true;           // replans: the whole submission replayed as one captured hipGraph
+    bool use_region = true;          // replans: one workgroup runs both phases in LDS on the block around the patch (ufm_region.h);
+                                     // the launch chain only takes over when work is left outside the block
+    int region_ahead = 2;            // block placement: tiles kept between the patches' centre and the block's goal-side edge
+    int region_tiles = 6;            // block edge in tiles (<= RTMAX; measured on the headline replans: 10 -> 6 tiles: 20.0 -> 18.6 ms per 100, same completion rate)
+    int region_sweeps = 4096;        // sweep budget per wave and phase
+    int region_debug = 0;
+    float region_band = 1.5f;        // ordering band of the block's lowering sub-rounds, in patch crossings at the mean cost (0: unordered)
+    uint32_t region_runs = 0, region_done = 0;   // replans submitted to the block kernel / completed by it alone
     int batch_margin = 1;            // replans: launches per phase = most that the last 6 replans needed + this
     float raise_margin = 0.25f;      // invalidation bound = start key + this many ordering bands (a miss costs a second round)
     ReplanJob *h_job = nullptr;      // host-coherent pinned: per-replan inputs of the graph's first node
@@ -2003,8 +2021,48 @@ int Engine::step(ufm_stats *out) {
         for (int i = 0; i < 6; ++i) { nr = std::max(nr, win_raise[i] + batch_margin); nl = std::max(nl, win_lower[i] + batch_margin); }
         const int k0_raise = iter[Q_RAISE], k0_lower = iter[Q_LOWER];
         if (profiling) while (ev.size() < 4) { hipEvent_t a; HIPCHK(hipEventCreate(&a)); ev.push_back(a); }
-        const bool graphed = fused && use_graph && nr < 250 && nl < 250;
-        if (graphed) {
+        // The block around the patches (ufm_region.h): its goal-side edge `region_ahead` tiles beyond the patches' centre,
+        // the rest of its extent behind it -- where the elements that lean on the patched cells are.
+        RegionJob rj{};
+        bool regioned = false;
+        if (fused && use_region && rb.nrect > 0) {
+            const bool nodes = algo != UFM_ALGO_DFM;
+            int ex0 = INT32_MAX, ex1 = -1, ey0 = INT32_MAX, ey1 = -1;
+            for (int r = 0; r < rb.nrect; ++r) {
+                const int *qr = rb.rect[r];
+                ex0 = std::min(ex0, qr[1]); ex1 = std::max(ex1, qr[1] + qr[4] - (nodes ? 0 : 1));
+                ey0 = std::min(ey0, qr[2]); ey1 = std::max(ey1, qr[2] + qr[3] - (nodes ? 0 : 1));
+            }
+            auto place = [&](int e0, int e1, int goal_e, int ntiles_map, int *t0, int *nt) {
+                *nt = std::min(std::min(region_tiles, RTMAX), ntiles_map);
+                const int tc = ((e0 + e1) / 2) / T;
+                int lo = (goal_e >= (e0 + e1) / 2) ? tc + region_ahead - *nt + 1 : tc - region_ahead;
+                lo = std::max(0, std::min(lo, ntiles_map - *nt));
+                *t0 = lo;
+                return e0 / T >= lo && e1 / T <= lo + *nt - 1;      // every consumed rectangle inside the block
+            };
+            const bool okx = place(ex0, ex1, maps[0].goal_ex, P.TX, &rj.tx0, &rj.ntx);
+            const bool oky = place(ey0, ey1, maps[0].goal_ey, P.TY, &rj.ty0, &rj.nty);
+            regioned = okx && oky;
+        }
+        const bool graphed = !regioned && fused && use_graph && nr < 250 && nl < 250;
+        if (regioned) {
+            rb.k_raise = iter[Q_RAISE]; rb.band = band;
+            rj.rb = rb; rj.dyn = dyn_now; rj.k_lower = iter[Q_LOWER]; rj.seq = ++pub_seq; rj.max_sweeps = region_sweeps; rj.debug = region_debug;
+            rj.slack = 255.0f * SQRT2F + 1.0f;     // the largest cost of one move (a diagonal through the most expensive cell)
+            rj.delta = region_band > 0.0f ? region_band * 4.0f * mean_cost : INFINITY;
+            dyn_dev = dyn_now; dyn_pending = false;
+            if (algo == UFM_ALGO_FD) k_replan_region<UFM_ALGO_FD><<<1, NTHR, 0, stream>>>(P, rj, h_ctr, h_flag);
+            else if (algo == UFM_ALGO_SG) k_replan_region<UFM_ALGO_SG><<<1, NTHR, 0, stream>>>(P, rj, h_ctr, h_flag);
+            else if (opt_lvl == 0) k_replan_region<UFM_ALGO_DFM><<<1, NTHR, 0, stream>>>(P, rj, h_ctr, h_flag);
+            else k_replan_region<ALGO_DFM1><<<1, NTHR, 0, stream>>>(P, rj, h_ctr, h_flag);
+            HIPCHK(hipGetLastError());
+            last_active = 1;
+            int rc = wait_published();
+            if (rc != UFM_OK) return rc;
+            ++region_runs;
+            if (h_ctr->done) ++region_done;
+        } else if (graphed) {
             rb.k_raise = iter[Q_RAISE]; rb.band = band;
             hipGraphExec_t ge = nullptr;
             int rc = replan_graph(nr, nl, band, &ge);
@@ -2065,11 +2123,14 @@ int Engine::step(ufm_stats *out) {
         }
         }   // !graphed
         updated += h_ctr->updated;
+        fast_done = h_ctr->done != 0;
+        if (regioned) {
+            st.launches += 1u;
+        } else {
         st.raise_launches += (uint32_t)nr;
         st.launches += (uint32_t)(nr + nl);
         // (launches replayed from the graph are not event-timed: HIP cannot read events recorded by graph nodes)
         if (profiling && !graphed) { st.timed_launches += (uint32_t)(nr + nl); st.timed_raise_launches += (uint32_t)nr; }
-        fast_done = h_ctr->done != 0;
         // launches the batches actually needed (for the next steps' batch sizes); a batch that was
         // too short costs a host round trip and the adaptive loop, so err on the long side after one
         {
@@ -2078,6 +2139,7 @@ int Engine::step(ufm_stats *out) {
             win_raise[win_pos] = fast_done ? need_r : nr + 2;
             win_lower[win_pos] = fast_done ? need_l : nl + 2;
             win_pos = (win_pos + 1) % 6;
+        }
         }
     } else if (have_seeds) {
         flush_dyn();
@@ -2198,6 +2260,7 @@ int Engine::step(ufm_stats *out) {
     st.queued_lower = (uint32_t)(h_ctr->cnt[Q_LOWER][iter[Q_LOWER] % 3] + h_ctr->npark[Q_LOWER]);   // parked beyond the start's key
     st.queued_raise = (uint32_t)(h_ctr->cnt[Q_RAISE][iter[Q_RAISE] % 3] + h_ctr->npark[Q_RAISE]);
     st.graphs_instantiated = graphs_made;
+    st.region_replans = region_runs; st.region_replans_done = region_done;
     st.u_ms = (float)u_acc;   // seeding + invalidation (the reference's update())
     st.p_ms = (float)p_acc;   // propagation + finalisation (the reference's plan())
     last = st;
@@ -2490,6 +2553,11 @@ int ufm_debug_tdiag(unsigned long long *out, int reset) {
     return UFM_OK;
 }
 #endif
+int ufm_debug_lmax(ufm_t *p, int32_t *out, int n) {      // diagnostics array of the device (not part of include/ufm.h)
+    if (!p || !p->e->allocated || n > LMAX) return UFM_ERR_INVALID;
+    hipStreamSynchronize(p->e->stream);
+    return hipMemcpy(out, p->e->P.lmax, sizeof(int) * n, hipMemcpyDeviceToHost) == hipSuccess ? UFM_OK : UFM_ERR_HIP_BASE;
+}
 int ufm_tile_edge(void) { return T; }
 const char *ufm_version(void) { return T == 32 ? "ufm-gfx950 0.1 (block-FIM, tile 32)" : "ufm-gfx950 0.1 (block-FIM, tile 16)"; }
 
@@ -2587,6 +2655,12 @@ static int engine_set_param(Engine *e, const char *name, double value) {
     else if (!std::strcmp(name, "spin_wait")) e->spin_wait = value != 0;
     else if (!std::strcmp(name, "fuse_control")) e->fuse_control = value != 0;
     else if (!std::strcmp(name, "graph")) e->use_graph = value != 0;
+    else if (!std::strcmp(name, "region")) e->use_region = value != 0;
+    else if (!std::strcmp(name, "region_debug")) e->region_debug = (int)value;
+    else if (!std::strcmp(name, "region_band")) e->region_band = (float)value;
+    else if (!std::strcmp(name, "region_ahead")) e->region_ahead = (int)value;
+    else if (!std::strcmp(name, "region_tiles")) e->region_tiles = value < 3 ? 3 : (value > RTMAX ? RTMAX : (int)value);
+    else if (!std::strcmp(name, "region_sweeps")) e->region_sweeps = value < 16 ? 16 : (int)value;
     else if (!std::strcmp(name, "batch_margin")) e->batch_margin = (int)value;
     else if (!std::strcmp(name, "raise_margin")) e->raise_margin = (float)value;
     else if (!std::strcmp(name, "tail_grid")) e->tail_grid = value < 1 ? 1 : (int)value;

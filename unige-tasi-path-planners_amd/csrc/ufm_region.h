@@ -1,0 +1,628 @@
+// ufm_region.h -- region-resident replan (included by ufm_engine.hip; shares its operators, queues and layout).
+//
+// What it replaces inside the engine: the launch chain of a replan -- k_replan_begin, ~9 invalidation launches,
+// k_raise_to_lower, ~9 lowering launches, k_replan_end, each launch a handful of tile visits on a 256-CU chip
+// (~230 us per replan, slower than one CPU core) -- i.e. the reference's update() + plan() after one patch_map
+// (FieldDPlanner_impl.h:118-163, :23-66; DynamicFastMarching_impl.h:13-132).
+//
+// How: a replan touches a few thousand elements around the patch.  ONE workgroup stages a block of up to
+// RTMAX x RTMAX tiles around the patch (field + 1-element frame + cost bytes, ~135 KB of the CU's 160 KB LDS) and
+// runs both phases there to their fixed point -- invalidation of what lost its support, then lowering -- with the
+// same per-patch asynchronous sweeps, wake bits and update operators as a tile visit of k_relax, but with no
+// kernel boundary, no HBM round trip and no queue traffic between the dependent steps.  The reference's
+// end_condition is honoured per element: a lowering result at or beyond the start's key (read from LDS, it moves
+// while the phase runs) and an invalidation of a value beyond the invalidation bound are not applied; their tiles
+// are parked in the persistent queues exactly as a tile visit would leave them.  Afterwards the block is written
+// back (changed values, neighbour rings), tiles outside the block whose halo changed are queued, and the same
+// device-side end condition as k_replan_end decides: nothing left below the start's key -> done, counters
+// published to the spinning host; otherwise the host carries on with the ordinary launch chain from the queues.
+// A sweep budget bounds every wave (livelock guard): what is still dirty when it runs out goes to the queues too.
+
+constexpr int RTMAX = 10;                 // block edge in tiles
+constexpr int RN = RTMAX * T;             // ... in elements (160)
+constexpr int RP = RN + 8;                // LDS pitch of the block's field: rows 4 apart on distinct banks (168 = 5*32 + 8)
+constexpr int RCP = RN + 4;               // pitch of the cost bytes
+constexpr int TP = T / 4;                 // 4x4-element patches per tile side
+constexpr int RPW = RTMAX * TP / 4;       // patches per wave per side: patch (pr, pc) belongs to wave ((pr & 3) << 2 | (pc & 3))
+constexpr int RWW = (RPW * RPW + 31) / 32;   // wake words per wave
+constexpr int RFRAME = 4 * RTMAX + 4;     // tiles around the block
+
+struct RegionJob {
+    ReplanBegin rb;                       // step bookkeeping, consumed patch rectangles, invalidation queue index, margin
+    DevDyn dyn;
+    int tx0, ty0, ntx, nty;               // the block, in tiles
+    int k_lower;                          // index of the next lowering launch (list the activations go to)
+    unsigned int seq;                     // sequence number to publish with
+    int max_sweeps;                       // sweep budget per wave and phase
+    int debug;                            // diagnostics.  bit 0: no end_condition gating inside the block; bit 1: the end check's inputs, event
+                                          // counts and a phase timeline go to the diagnostics array (ufm_debug_lmax, tools/replan_timeline.py)
+    float slack;                          // lowering results up to this far beyond the start's key are still applied (see Bgate)
+    float delta;                          // width of the ordering band of the lowering sub-rounds (cost units; +inf: no ordering)
+};
+
+// counters the block kernel shares between its phases (LDS)
+struct RegionShared {
+    int wake[16][RWW];                    // per wave: patches with new inputs
+    int ever[16][RWW];                    // patches swept by the invalidation phase (they are re-lowered)
+    int defer[2][16][RWW];                // patches holding results beyond the bound (lower / raise)
+    int dprio[2][RTMAX * RTMAX];          // per tile: smallest deferred priority (float bits)
+    int tflag[RTMAX * RTMAX];             // tile has changed values
+    int traised[RTMAX * RTMAX];           // the invalidation took a value away in this tile: then it takes away EVERY unsupported one of the tile
+    int actL[RFRAME], actR[RFRAME];       // per tile of the frame: smallest lowered / invalidated border value next to it
+    int soff[4];                          // start elements inside the block: LDS offset (-1: outside / unused)
+    float sdist[4];                       // hm * dist(start, element)
+    float B0, rbound;
+    float theta;                          // ordering: lowering results at / above it wait for a later sub-round (tile-engine band, per patch)
+    float Bgate;                          // min(Bsub + slack, theta): what the bursts compare with.  The slack is one maximal
+                                          // traversal step: every element NEXT to one inside the bound still gets its value, as in the
+                                          // reference, where expanding an element computes the RHS of all its neighbours (the path
+                                          // extractor reads RHS around the start: FieldDPlanner_impl.h:44-52, PathExtraction impl:76-77)
+    int rmin;                             // smallest value the invalidation took away (float bits)
+    float Bsub;                           // the bound lowering results are held against during the current sub-round
+    int swas[4];                          // start element held a finite value when the kernel started
+    int idle, giveup, again, any_start_in;
+    unsigned long long sweeps;
+    int expanded;
+    int m_r, m_l, done;
+    int dkey;                             // smallest KEY (value + hm * dist) lowering held back in the current sub-round (float bits)
+    int dbg[8];                           // diagnostics
+    unsigned long long tstamp[12];        // diagnostics: wall_clock64 at the phase boundaries
+};
+
+// the start's key from the block (elements outside the block cannot change while the kernel runs: B0 covers them)
+__device__ __forceinline__ float region_start_key(const float *Gs, const RegionShared &S) {
+    if (!S.any_start_in) return S.B0;
+    float b = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int o = S.soff[i];
+        if (o < 0) continue;
+        const float g = Gs[o];
+        if (g < INFINITY) b = fmaxf(b, g + S.sdist[i]);
+    }
+    return b > 0.0f ? b : INFINITY;
+}
+
+// The bound of a lowering sub-round.  It is FIXED while the sub-round runs -- so that what gets applied does not depend
+// on which wave looked at the start's key when (results reproducible from run to run) -- and it is the start's key
+// unless a start element that had a value when the kernel began has lost it to the invalidation and not yet got it
+// back: then nobody knows the key yet, and the invalidation bound (old key + margin) stands in for it, instead of
+// "no bound at all" (which floods the whole block, every time the patch lies on the start -- as it does in the
+// harness's reveal-around-the-robot patches).  The check at quiescence re-opens what a too small bound held back.
+__device__ __forceinline__ float region_lower_bound(const float *Gs, const RegionShared &S) {
+    if (!S.any_start_in) return S.B0;
+    float b = 0.0f;
+    bool pending = false;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int o = S.soff[i];
+        if (o < 0) continue;
+        const float g = Gs[o];
+        if (g < INFINITY) b = fmaxf(b, g + S.sdist[i]);
+        else if (S.swas[i]) pending = true;
+    }
+    if (pending) return fmaxf(b, S.rbound);
+    return b > 0.0f ? b : INFINITY;
+}
+
+// One phase (MODE_RAISE: invalidation, MODE_LOWER: lowering) of the block to quiescence.  All 16 waves call.
+template <int ALGO, int MODE>
+__device__ void region_phase(const DevParams &P, const RegionJob &J, float *Gs, const uint8_t *Cb, RegionShared &S,
+                             int thr, float hm, int focused, int goal_lx, int goal_ly) {
+    const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
+    const int q = lane & 3, nd = lane >> 2;
+    const int nprow = J.ntx * TP, npcol = J.nty * TP;
+    unsigned long long wake_sel = 0ull;
+    if (lane < 9) {
+        const int dr = lane / 3 - 1, dc = lane % 3 - 1;
+        wake_sel = ~0ull;
+        if (dr < 0) wake_sel &= 0x000000000000FFFFull; else if (dr > 0) wake_sel &= 0xFFFF000000000000ull;
+        if (dc < 0) wake_sel &= 0x000F000F000F000Full; else if (dc > 0) wake_sel &= 0xF000F000F000F000ull;
+    }
+    const int colour = ((nd >> 2) & 1) | ((nd & 1) << 1);
+    const float sx = P.spos[0], sy = P.spos[1];
+    const int rx0 = J.tx0 * T, ry0 = J.ty0 * T;
+    long long budget = J.max_sweeps;
+    unsigned long long my_sweeps = 0;
+    auto cost_at = [=](int r, int c) { const int b = Cb[r * RCP + c]; return b >= thr ? INFINITY : (float)b; };
+    for (;;) {
+        bool took = false;
+        bool vote = __hip_atomic_load(&S.giveup, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != 0;
+        for (int wd = 0; wd < RWW && !vote; ++wd) {
+            int bits = 0;
+            if (lane == 0) bits = atomicExch(&S.wake[w][wd], 0);
+            bits = __builtin_amdgcn_readfirstlane(bits);
+            if (!bits) continue;
+            if (MODE == MODE_RAISE && lane == 0) S.ever[w][wd] |= bits;      // only this wave writes its own words
+            while (bits) {
+                const int j = __ffs(bits) - 1;
+                if (budget <= 0) {                                           // out of budget: leave the rest for the queues
+                    if (lane == 0) {
+                        __hip_atomic_fetch_or(&S.wake[w][wd], bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        __hip_atomic_store(&S.giveup, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    }
+                    vote = true;
+                    break;
+                }
+                bits &= bits - 1;
+                took = true;
+                const int idx = wd * 32 + j;
+                const int pr = (idx / RPW) * 4 + (w >> 2), pc = (idx % RPW) * 4 + (w & 3);
+                if (pr >= nprow || pc >= npcol) continue;                    // (never woken; a block smaller than RTMAX)
+                const int lx = pr * 4 + (nd >> 2), ly = pc * 4 + (nd & 3);
+                QuadConsts<ALGO> C;
+                C.load_at(cost_at, lx, ly, q, RP);
+                float *ctr = Gs + (lx + 1) * RP + ly + 1;
+                const bool goal = (lx == goal_lx) & (ly == goal_ly);
+                // wake targets: lane 0..8 = the 3x3 patches around this one (lane 4: itself)
+                int nwave = 0, nword = -1, nbit = 0;
+                if (lane < 9) {
+                    const int npr = pr + lane / 3 - 1, npc = pc + lane % 3 - 1;
+                    if (npr >= 0 && npr < nprow && npc >= 0 && npc < npcol) {
+                        nwave = ((npr & 3) << 2) | (npc & 3);
+                        const int ni = (npr >> 2) * RPW + (npc >> 2);
+                        nword = ni >> 5; nbit = 1 << (ni & 31);
+                    }
+                }
+                // admissible part of the key that does not depend on the value: hm * dist(start, patch)
+                float hd = 0.0f;
+                if (hm != 0.0f) {
+                    const float x0 = (float)(rx0 + pr * 4), x1 = x0 + 3.0f, y0 = (float)(ry0 + pc * 4), y1 = y0 + 3.0f;
+                    const float dx = fmaxf(fmaxf(x0 - sx, sx - x1), 0.0f), dy = fmaxf(fmaxf(y0 - sy, sy - y1), 0.0f);
+                    hd = hm * hypotf(dx, dy) * 0.999f;
+                }
+                const int tl = (pr / TP) * J.nty + (pc / TP);
+                // the sub-round's bound (region_lower_bound); a start element itself is never held back
+                const float B = (MODE == MODE_LOWER) ? S.Bgate : INFINITY;
+                const int my_off = (lx + 1) * RP + ly + 1;
+                const bool is_start = (my_off == S.soff[0]) | (my_off == S.soff[1]) | (my_off == S.soff[2]) | (my_off == S.soff[3]);
+                // Invalidation is held back beyond the bound per TILE, like a tile visit of k_relax: once a tile has lost a value,
+                // every unsupported value in it goes, whatever its size.  (Holding back single elements would leave unsupported
+                // values NEXT to invalidated ones: the lowering phase -- this one with its one-move slack, or the launch chain's
+                // tile visits, which do not look at single values -- would then rebuild the hole from them.)
+                const float rb = S.traised[tl] ? INFINITY : S.rbound + J.slack;
+                asm volatile("" ::: "memory");
+                float g = ctr[0];
+                float dmin = INFINITY;                                        // smallest priority this lane deferred
+                bool again = true;
+                int cnt = 0;
+                for (int b = 0; b < 16 && again; ++b) {
+                    asm volatile("" ::: "memory");                          // re-read the block every sweep (other waves write it)
+                    float nv = quad_min(eval_quad<ALGO, RP>(ctr, q, C));
+                    if (goal) nv = 0.0f;
+                    bool want, gate, doit;
+                    if (MODE == MODE_LOWER) {
+                        want = (nv != g);
+                        gate = (nv + hd < B) | (B == INFINITY) | is_start | ((J.debug & 1) != 0);    // end_condition: results at / beyond the start's key wait
+                        doit = want & gate & ((nv < g) | (colour == (cnt & 3)));
+                        if (want & !gate) dmin = fminf(dmin, nv);
+                    } else {
+                        if (is_dfm<ALGO>) want = (g < INFINITY) & (nv > g) & ((nv == INFINITY) | (__float_as_int(nv) - __float_as_int(g) > 8));
+                        else want = (g < INFINITY) & (nv > g);
+                        gate = !(g > rb) | ((J.debug & 1) != 0);                                     // beyond the invalidation bound: wait
+                        doit = want & gate;
+                        if (want & !gate) dmin = fminf(dmin, g);
+                        if (doit & (q == 0)) { atomicMin(&S.rmin, __float_as_int(g)); S.traised[tl] = 1; }
+                        nv = INFINITY;
+                    }
+                    if (doit && q == 0) ctr[0] = nv;
+                    const float gn = doit ? nv : g;
+                    const unsigned long long mask = __builtin_amdgcn_ballot_w64(gn != g);
+                    const unsigned long long wanted = __builtin_amdgcn_ballot_w64(want & gate);   // lanes not yet settled (a colour-gated rise waits for its sweep)
+                    g = gn;
+                    UFM_SWEEP_FENCE();                                        // value before wake bit
+                    if (mask != 0ull && lane == 0) S.tflag[tl] = 1;             // the tile holds changed values (write-back looks at these tiles only)
+                    if ((mask & wake_sel) != 0ull && nword >= 0 && lane != 4)
+                        __hip_atomic_fetch_or(&S.wake[nwave][nword], nbit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    ++cnt;
+                    again = wanted != 0ull;
+                }
+                budget -= cnt; my_sweeps += cnt;
+                if ((J.debug & 2) && lane == 0) { atomicAdd(&S.dbg[MODE == MODE_LOWER ? 5 : 4], 1); atomicAdd(&S.dbg[MODE == MODE_LOWER ? 7 : 6], cnt); }
+                if (again && lane == 0) __hip_atomic_fetch_or(&S.wake[w][wd], 1 << j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // burst cap
+                if (dmin < INFINITY && q == 0) {
+                    atomicAdd(&S.dbg[MODE == MODE_LOWER ? 0 : 1], 1);
+                    atomicMin(&S.dprio[MODE == MODE_LOWER ? 0 : 1][tl], __float_as_int(dmin));      // the tile's priority when it is parked
+                    if (MODE == MODE_LOWER) atomicMin(&S.dkey, __float_as_int(dmin + hd));          // what the gate compared with the start's key
+                    __hip_atomic_fetch_or(&S.defer[MODE == MODE_LOWER ? 0 : 1][w][wd], 1 << j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
+            }
+        }
+        if (took && !vote) continue;
+        if (!vote) {                                                         // nothing to do: idle until woken or all idle
+            if (lane == 0) atomicAdd(&S.idle, 1);
+            for (;;) {
+                __builtin_amdgcn_s_sleep(UFM_IDLE_SLEEP);
+                if (__hip_atomic_load(&S.idle, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >= 16 ||
+                    __hip_atomic_load(&S.giveup, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != 0) { vote = true; break; }
+                int any = 0;
+#pragma unroll
+                for (int wd = 0; wd < RWW; ++wd) any |= __hip_atomic_load(&S.wake[w][wd], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                if (any) { if (lane == 0) atomicSub(&S.idle, 1); break; }
+            }
+            if (!vote) continue;
+        }
+        // vote: everybody arrives first, then the wake bits are stable
+        __syncthreads();
+        int mine = 0;
+#pragma unroll
+        for (int wd = 0; wd < RWW; ++wd) mine |= __hip_atomic_load(&S.wake[w][wd], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        const int work = __syncthreads_or(mine != 0);
+        const int gave_up = __hip_atomic_load(&S.giveup, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (gave_up || !work) break;
+        if (tid == 0) S.idle = 0;
+        __syncthreads();
+    }
+    if (lane == 0 && my_sweeps) atomicAdd(&S.sweeps, my_sweeps);
+    __syncthreads();
+    if (tid == 0) S.idle = 0;
+    __syncthreads();
+}
+
+template <int ALGO>
+__global__ __launch_bounds__(NTHR) void k_replan_region(DevParams P, RegionJob J, DevCounters *host, unsigned int *flag) {
+    __shared__ float Gs[(RN + 2) * RP];
+    __shared__ uint8_t Cb[(RN + 1) * RCP];
+    __shared__ RegionShared S;
+    constexpr bool CELLS = is_dfm<ALGO>;
+    constexpr int COFF = CELLS ? 0 : 1;
+    const int tid = threadIdx.x;
+    const int ntl = J.ntx * J.nty;
+    const int rx0 = J.tx0 * T, ry0 = J.ty0 * T, rnx = J.ntx * T, rny = J.nty * T;
+
+    const unsigned long long t_begin = wall_clock64();
+    // ---- 0. what k_replan_begin does: step bookkeeping, mark reset, the seeds, the invalidation bound ----
+    if (tid == 0) *P.dyn = J.dyn;
+    step_begin(P, J.rb.sb);
+    for (int r = 0; r < J.rb.nrect; ++r) {
+        const int *qr = J.rb.rect[r];
+        for (int e = tid; e < (qr[3] + 1) * (qr[4] + 1); e += NTHR) clear_mark(P, qr[0], qr[1], qr[2], qr[3], qr[4], e);
+    }
+    for (int i = tid; i < (int)(sizeof(RegionShared) / sizeof(int)); i += NTHR) reinterpret_cast<int *>(&S)[i] = 0;
+    __syncthreads();
+    for (int i = tid; i < 2 * RTMAX * RTMAX; i += NTHR) (&S.dprio[0][0])[i] = INFBITS;
+    for (int i = tid; i < RFRAME; i += NTHR) { S.actL[i] = INFBITS; S.actR[i] = INFBITS; }
+    if (tid == 0) S.rmin = INFBITS;
+    const float hm = J.dyn.hm;
+    const int thr = J.dyn.thr, focused = J.dyn.focused;
+    {   // pending seeds (single map, all consumed): tiles inside the block are handled here, any other goes to the queue
+        const int n = P.ctr->scount;
+        for (int i = tid; i < n; i += NTHR) {
+            const int gt = P.slist[i];
+            const int tx = gt / P.TY, ty = gt - tx * P.TY;
+            P.sflag[gt] = 0;
+            if (tx < J.tx0 || tx >= J.tx0 + J.ntx || ty < J.ty0 || ty >= J.ty0 + J.nty) activate(P, Q_RAISE, J.rb.k_raise % 3, J.rb.k_raise & 1, gt, 0);
+        }
+        __syncthreads();
+        if (tid == 0) {
+            P.ctr->scount = 0;
+            const float b0 = start_bound(P, 0);            // the start's key before the patch (step_begin stored the start)
+            S.B0 = b0;
+            S.rbound = focused ? b0 + J.rb.band : INFINITY;
+            P.ctr->done = 0;
+            bool in = false;
+            for (int i = 0; i < 4; ++i) {
+                const int e = J.rb.sb.start[i];
+                S.soff[i] = -1; S.sdist[i] = 0.0f;
+                if (e < 0) continue;
+                const int x = e / P.EY, y = e - x * P.EY;
+                S.sdist[i] = hm * hypotf(J.rb.sb.sx - (float)x, J.rb.sb.sy - (float)y);
+                if (x >= rx0 && x < rx0 + rnx && y >= ry0 && y < ry0 + rny) { S.soff[i] = (x - rx0 + 1) * RP + (y - ry0 + 1); in = true; }
+            }
+            S.any_start_in = in ? 1 : 0;
+        }
+    }
+
+    if (tid == 0) { S.tstamp[0] = t_begin; S.tstamp[1] = wall_clock64(); }
+    // ---- 1. stage the block: tiles (contiguous 1 KB each), the 1-element frame around it, the cost bytes ----
+    for (int i = tid; i < ntl * TT; i += NTHR) {
+        const int tl = i / TT, e = i - tl * TT, ti = tl / J.nty, tj = tl - ti * J.nty;
+        const int gt = (J.tx0 + ti) * P.TY + J.ty0 + tj;
+        Gs[(ti * T + e / T + 1) * RP + tj * T + e % T + 1] = P.G[(size_t)gt * TT + e];
+    }
+    for (int i = tid; i < 2 * (rny + 2) + 2 * rnx; i += NTHR) {
+        int hx, hy;
+        if (i < rny + 2) { hx = -1; hy = i - 1; }
+        else if (i < 2 * (rny + 2)) { hx = rnx; hy = i - (rny + 2) - 1; }
+        else if (i < 2 * (rny + 2) + rnx) { hx = i - 2 * (rny + 2); hy = -1; }
+        else { hx = i - 2 * (rny + 2) - rnx; hy = rny; }
+        const int x = rx0 + hx, y = ry0 + hy;
+        const bool in = x >= 0 && y >= 0 && x < P.TX * T && y < P.TY * T;
+        Gs[(hx + 1) * RP + hy + 1] = in ? P.G[gaddr(P, 0, x, y)] : INFINITY;
+    }
+    {
+        const int crow = rnx + COFF, ccol = rny + COFF;
+        for (int i = tid; i < crow * ccol; i += NTHR) {
+            const int r = i / ccol, c = i - r * ccol;
+            const int cx = rx0 + r - COFF, cy = ry0 + c - COFF;
+            Cb[r * RCP + c] = (cx >= 0 && cy >= 0 && cx < P.L && cy < P.W) ? P.cost[(size_t)cx * P.W + cy] : (uint8_t)255;
+        }
+    }
+    // the seeds: every patch that holds an element of a consumed rectangle (a superset of the changed cells' elements;
+    // a sweep that finds nothing to do costs a fraction of a microsecond)
+    __syncthreads();
+    for (int r = 0; r < J.rb.nrect; ++r) {
+        const int *qr = J.rb.rect[r];                       // {map, x, y, w, h}: cells x..x+h-1, y..y+w-1
+        const int ex0 = qr[1] - rx0, ex1 = qr[1] + qr[4] - (CELLS ? 1 : 0) - rx0, ey0 = qr[2] - ry0, ey1 = qr[2] + qr[3] - (CELLS ? 1 : 0) - ry0;
+        const int p0 = max(ex0, 0) / 4, p1 = min(ex1, rnx - 1) / 4, c0 = max(ey0, 0) / 4, c1 = min(ey1, rny - 1) / 4;
+        const int np = (p1 - p0 + 1) * (c1 - c0 + 1);
+        for (int i = tid; i < np; i += NTHR) {
+            const int pr = p0 + i / (c1 - c0 + 1), pc = c0 + i % (c1 - c0 + 1);
+            const int ni = (pr >> 2) * RPW + (pc >> 2);
+            atomicOr(&S.wake[((pr & 3) << 2) | (pc & 3)][ni >> 5], 1 << (ni & 31));
+            S.traised[(pr / TP) * J.nty + pc / TP] = 1;      // a seeded tile is invalidated without a bound (the launch chain queues seeds with priority 0)
+        }
+    }
+    if (tid == 0) S.tstamp[2] = wall_clock64();
+    if (tid < 4) S.swas[tid] = (S.soff[tid] >= 0 && Gs[S.soff[tid]] < INFINITY) ? 1 : 0;
+    __syncthreads();
+    const int goal_lx = P.goal[0] - rx0, goal_ly = P.goal[1] - ry0;
+
+    // ---- 2. invalidate, lower; again while an invalidation that was held back lies below the start's new key ----
+    for (int round = 0;; ++round) {
+        for (;;) {
+            region_phase<ALGO, MODE_RAISE>(P, J, Gs, Cb, S, thr, hm, focused, goal_lx, goal_ly);
+            if (tid == 0) {        // a tile that lost a value after some of its patches had been held back: those patches again
+                int again = 0;
+                for (int i = 0; i < ntl; ++i) again |= (S.traised[i] && S.dprio[1][i] != INFBITS) ? 1 : 0;
+                S.again = (again && !S.giveup) ? 1 : 0;
+            }
+            __syncthreads();
+            const int again_t = S.again;
+            __syncthreads();
+            if (!again_t) break;
+            for (int i = tid; i < 16 * RWW; i += NTHR) { (&S.wake[0][0])[i] |= (&S.defer[1][0][0])[i]; (&S.defer[1][0][0])[i] = 0; }
+            for (int i = tid; i < RTMAX * RTMAX; i += NTHR) S.dprio[1][i] = INFBITS;
+            __syncthreads();
+        }
+        if (tid == 0 && round == 0) S.tstamp[3] = wall_clock64();
+        // everything the invalidation swept is re-lowered (plus, in later rounds, what lowering had to hold back)
+        for (int i = tid; i < 16 * RWW; i += NTHR) {
+            (&S.wake[0][0])[i] |= (&S.ever[0][0])[i] | (&S.defer[0][0][0])[i];
+            (&S.ever[0][0])[i] = 0; (&S.defer[0][0][0])[i] = 0;
+        }
+        for (int i = tid; i < RTMAX * RTMAX; i += NTHR) S.dprio[0][i] = INFBITS;
+        if (tid == 0) {
+            S.dkey = INFBITS;
+            S.Bsub = focused ? region_lower_bound(Gs, S) : INFINITY;
+            // the first band: everything below the smallest value that was taken away, plus one band width (a step without
+            // invalidations is not ordered: its few lowered values sit around the patch)
+            S.theta = (round == 0) ? ((S.rmin != INFBITS) ? __int_as_float(S.rmin) + J.delta : INFINITY) : S.theta;
+            S.Bgate = fminf(S.Bsub + J.slack, S.theta);
+        }
+        __syncthreads();
+        for (int sub = 0;; ++sub) {
+            region_phase<ALGO, MODE_LOWER>(P, J, Gs, Cb, S, thr, hm, focused, goal_lx, goal_ly);
+            // the start's key may have risen while results were being held back against an earlier value of it
+            if (tid == 0) {
+                const float B = focused ? region_lower_bound(Gs, S) : INFINITY;
+                const int m = S.dkey;
+                bool again = !S.giveup && m != INFBITS && (__int_as_float(m) < B || B == INFINITY);
+                if (again && sub >= 4096) { again = false; S.giveup = 1; }   // (never seen; what is dirty goes to the queues)
+                S.again = again ? 1 : 0;
+                S.Bsub = B;
+                if (again) S.theta = fmaxf(S.theta, __int_as_float(m)) + J.delta;    // the next band starts where work is waiting
+                S.Bgate = fminf(S.Bsub + J.slack, S.theta);
+            }
+            __syncthreads();
+            const int again_l = S.again;
+            __syncthreads();                    // (thread 0 overwrites the word below: everyone has read it first)
+            if (!again_l) break;
+            if (tid == 0) ++S.dbg[2];
+            for (int i = tid; i < 16 * RWW; i += NTHR) { (&S.wake[0][0])[i] |= (&S.defer[0][0][0])[i]; (&S.defer[0][0][0])[i] = 0; }
+            for (int i = tid; i < RTMAX * RTMAX; i += NTHR) S.dprio[0][i] = INFBITS;
+            if (tid == 0) S.dkey = INFBITS;
+            __syncthreads();
+        }
+        if (tid == 0) {
+            const float B = focused ? region_lower_bound(Gs, S) : INFINITY;
+            int m = INFBITS;
+            for (int i = 0; i < ntl; ++i) m = min(m, S.dprio[1][i]);
+            bool again = !S.giveup && focused && m != INFBITS && __int_as_float(m) < B + J.slack;   // lowering reaches the key plus one move
+            if (again && round >= 14) { again = false; S.giveup = 1; }
+            if (again) S.rbound = fmaxf(B, S.rbound) + J.rb.band;
+            S.again = again ? 1 : 0;
+        }
+        __syncthreads();
+        const int again_r = S.again;
+        __syncthreads();
+        if (!again_r) break;
+        if (tid == 0) ++S.dbg[3];
+        for (int i = tid; i < 16 * RWW; i += NTHR) { (&S.wake[0][0])[i] |= (&S.defer[1][0][0])[i]; (&S.defer[1][0][0])[i] = 0; }
+        for (int i = tid; i < RTMAX * RTMAX; i += NTHR) S.dprio[1][i] = INFBITS;
+        __syncthreads();
+    }
+
+    if (tid == 0) S.tstamp[4] = wall_clock64();
+    // ---- 3. write back: changed values, the rings of the neighbours they border, what the frame has to hear ----
+    // frame tile index of the tile at block coordinates (ti, tj), ti in -1..ntx, tj in -1..nty (one of them outside)
+    auto frame_index = [&](int ti, int tj) {
+        if (ti < 0) return tj + 1;                                   // top row: 0 .. nty+1
+        if (ti >= J.ntx) return (J.nty + 2) + tj + 1;                // bottom row
+        if (tj < 0) return 2 * (J.nty + 2) + ti;                     // left column
+        return 2 * (J.nty + 2) + J.ntx + ti;                         // right column
+    };
+    constexpr int PER = (RTMAX * RTMAX * TT + NTHR - 1) / NTHR;      // elements per thread (25)
+    float init[PER];
+    int n_exp = 0;
+#pragma unroll
+    for (int it = 0; it < PER; ++it) {
+        const int i = tid + it * NTHR;
+        init[it] = 0.0f;
+        if (i >= ntl * TT) continue;
+        const int tl = i / TT, e = i - tl * TT, ti = tl / J.nty, tj = tl - ti * J.nty;
+        if (!S.tflag[tl]) continue;                                         // nothing was applied in this tile
+        const int tx = J.tx0 + ti, ty = J.ty0 + tj, gt = tx * P.TY + ty;
+        const int io_r = e / T, io_c = e % T;
+        const float gl0 = P.G[(size_t)gt * TT + e];
+        const float gf = Gs[(ti * T + io_r + 1) * RP + tj * T + io_c + 1];
+        init[it] = gl0;
+        if (gf == gl0) continue;
+        ++n_exp;
+        P.G[(size_t)gt * TT + e] = gf;
+        const int er = (io_r == 0) ? -1 : ((io_r == T - 1) ? 1 : 0);
+        const int ec = (io_c == 0) ? -1 : ((io_c == T - 1) ? 1 : 0);
+        const bool rok = er && tx + er >= 0 && tx + er < P.TX, cok = ec && ty + ec >= 0 && ty + ec < P.TY;
+        if (rok) P.ring[(size_t)(gt + er * P.TY) * RING + (er < 0 ? RING_BOT : RING_TOP) + io_c] = gf;
+        if (cok) P.ring[(size_t)(gt + ec) * RING + (ec < 0 ? RING_RIGHT : RING_LEFT) + io_r] = gf;
+        if (rok && cok) P.ring[(size_t)(gt + er * P.TY + ec) * RING + RING_CORNER + (er < 0 ? 2 : 0) + (ec < 0 ? 1 : 0)] = gf;
+        // neighbours outside the block: lowered value -> lowering queue, lost / raised value -> invalidation queue,
+        // each only if an element of that neighbour (the frame, as staged) can be concerned at all (causality, see k_relax)
+        const bool out_r = rok && (ti + er < 0 || ti + er >= J.ntx), out_c = cok && (tj + ec < 0 || tj + ec >= J.nty);
+        if (!(out_r || out_c)) continue;
+        const int lxr = ti * T + io_r + 1, lyc = tj * T + io_c + 1;          // position in Gs
+        const int cl = max(io_c - 1, 0) - io_c, ch = min(io_c + 1, T - 1) - io_c;   // columns / rows of the edge neighbour itself
+        const int rl = max(io_r - 1, 0) - io_r, rh = min(io_r + 1, T - 1) - io_r;
+        const float lo = fminf(gf, gl0);
+        const bool lowered = gf < gl0;
+        const int pb = __float_as_int(lowered ? gf : gl0);
+        auto concerned = [&](float a, float b, float c) {
+            if (lowered) return lo < fmaxf(fmaxf(a, b), c);                  // someone above the new value
+            const float fa = a < INFINITY ? a : -INFINITY, fb = b < INFINITY ? b : -INFINITY, fc = c < INFINITY ? c : -INFINITY;
+            return gl0 < fmaxf(fmaxf(fa, fb), fc);                          // someone (finite) above the old value may have leaned on it
+        };
+        if (out_r) {
+            const float *h = Gs + (lxr + er) * RP + lyc;
+            if (concerned(h[cl], h[0], h[ch])) atomicMin(lowered ? &S.actL[frame_index(ti + er, tj)] : &S.actR[frame_index(ti + er, tj)], pb);
+        }
+        if (out_c) {
+            const float *h = Gs + lxr * RP + lyc + ec;
+            if (concerned(h[rl * RP], h[0], h[rh * RP])) atomicMin(lowered ? &S.actL[frame_index(ti, tj + ec)] : &S.actR[frame_index(ti, tj + ec)], pb);
+        }
+        if (rok && cok && (out_r || out_c)) {                               // the diagonal neighbour
+            const int di = ti + er, dj = tj + ec;
+            if (di < 0 || di >= J.ntx || dj < 0 || dj >= J.nty) {
+                const float hv = Gs[(lxr + er) * RP + lyc + ec];
+                if (concerned(hv, hv, hv)) atomicMin(lowered ? &S.actL[frame_index(di, dj)] : &S.actR[frame_index(di, dj)], pb);
+            }
+        }
+    }
+    if (n_exp) atomicAdd(&S.expanded, n_exp);
+    __syncthreads();
+    // frame tiles -> queues; held-back results -> park lists; what a budget overrun left dirty -> queues
+    for (int i = tid; i < 2 * (J.nty + 2) + 2 * J.ntx; i += NTHR) {
+        int ti, tj;
+        if (i < J.nty + 2) { ti = -1; tj = i - 1; }
+        else if (i < 2 * (J.nty + 2)) { ti = J.ntx; tj = i - (J.nty + 2) - 1; }
+        else if (i < 2 * (J.nty + 2) + J.ntx) { ti = i - 2 * (J.nty + 2); tj = -1; }
+        else { ti = i - 2 * (J.nty + 2) - J.ntx; tj = J.nty; }
+        const int tx = J.tx0 + ti, ty = J.ty0 + tj;
+        if (tx < 0 || ty < 0 || tx >= P.TX || ty >= P.TY) continue;
+        const int gt = tx * P.TY + ty;
+        if (S.actR[i] != INFBITS) activate(P, Q_RAISE, J.rb.k_raise % 3, J.rb.k_raise & 1, gt, S.actR[i]);
+        if (S.actL[i] != INFBITS) activate(P, Q_LOWER, J.k_lower % 3, J.k_lower & 1, gt, S.actL[i]);
+    }
+    for (int tl = tid; tl < ntl; tl += NTHR) {
+        const int gt = (J.tx0 + tl / J.nty) * P.TY + J.ty0 + tl % J.nty;
+        if (S.dprio[0][tl] != INFBITS) park_tile(P, Q_LOWER, gt, S.dprio[0][tl]);
+        if (S.dprio[1][tl] != INFBITS) park_tile(P, Q_RAISE, gt, S.dprio[1][tl]);
+    }
+    if (S.giveup) {
+        for (int i = tid; i < 16 * RWW * 32; i += NTHR) {
+            const int w = i / (RWW * 32), r = i % (RWW * 32);
+            if (!(S.wake[w][r >> 5] & (1 << (r & 31)))) continue;
+            const int pr = (r / RPW) * 4 + (w >> 2), pc = (r % RPW) * 4 + (w & 3);
+            if (pr >= J.ntx * TP || pc >= J.nty * TP) continue;
+            const int gt = (J.tx0 + pr / TP) * P.TY + J.ty0 + pc / TP;
+            activate(P, Q_RAISE, J.rb.k_raise % 3, J.rb.k_raise & 1, gt, 0);      // invalidation first, then (k_touched_to_active) lowering
+            activate(P, Q_LOWER, J.k_lower % 3, J.k_lower & 1, gt, 0);
+        }
+    }
+    __threadfence();
+    __syncthreads();
+
+    if (tid == 0) S.tstamp[5] = wall_clock64();
+    // ---- 4. the device-side end condition (as k_replan_end): is anything left below the start's key? ----
+    if (tid == 0) { S.m_r = INFBITS; S.m_l = INFBITS; }
+    __syncthreads();
+    {
+        const float B = focused ? region_start_key(Gs, S) : INFINITY;
+        int mr = INFBITS, ml = INFBITS;
+        const int nr = __hip_atomic_load(&P.ctr->cnt[Q_RAISE][J.rb.k_raise % 3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (int i = tid; i < nr; i += NTHR) {
+            const int gt = __hip_atomic_load(&P.cand[(size_t)(Q_RAISE * 3 + J.rb.k_raise % 3) * P.NT + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            mr = min(mr, __hip_atomic_load(&P.prio[(size_t)(Q_RAISE * 2 + (J.rb.k_raise & 1)) * P.NT + gt], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        }
+        const int npr = __hip_atomic_load(&P.ctr->npark[Q_RAISE], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (int i = tid; i < npr; i += NTHR) {
+            const int gt = __hip_atomic_load(&P.park[(size_t)(Q_RAISE * 2) * P.NT + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            mr = min(mr, __hip_atomic_load(&P.pprio[Q_RAISE * P.NT + gt], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        }
+        auto lower_key = [&](int gt, int pbits) {      // smallest key an element of the tile can have: priority + hm * dist(start, tile)
+            if (pbits == INFBITS) return INFINITY;
+            return __int_as_float(pbits) + (focused ? tile_heuristic(P, 0, gt / P.TY, gt % P.TY) : 0.0f);
+        };
+        float kl = INFINITY;
+        const int nl = __hip_atomic_load(&P.ctr->cnt[Q_LOWER][J.k_lower % 3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (int i = tid; i < nl; i += NTHR) {
+            const int gt = __hip_atomic_load(&P.cand[(size_t)(Q_LOWER * 3 + J.k_lower % 3) * P.NT + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            kl = fminf(kl, lower_key(gt, __hip_atomic_load(&P.prio[(size_t)(Q_LOWER * 2 + (J.k_lower & 1)) * P.NT + gt], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)));
+        }
+        const int npl = __hip_atomic_load(&P.ctr->npark[Q_LOWER], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (int i = tid; i < npl; i += NTHR) {
+            const int gt = __hip_atomic_load(&P.park[(size_t)(Q_LOWER * 2) * P.NT + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            kl = fminf(kl, lower_key(gt, __hip_atomic_load(&P.pprio[Q_LOWER * P.NT + gt], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)));
+        }
+        ml = kl < INFINITY ? __float_as_int(kl) : INFBITS;
+        if (mr != INFBITS) atomicMin(&S.m_r, mr);
+        if (ml != INFBITS) atomicMin(&S.m_l, ml);
+        __syncthreads();
+        if (tid == 0) {
+            bool done;
+            if (focused && B < INFINITY) done = !(__int_as_float(S.m_r) < B) && !(__int_as_float(S.m_l) < B);
+            else done = (nr == 0 && nl == 0 && (focused ? (S.m_r == INFBITS && S.m_l == INFBITS) : true));
+            if (S.giveup) done = false;
+            S.done = done ? 1 : 0;
+            P.ctr->done = S.done;
+            P.ctr->rbound = S.rbound;
+            P.ctr->qmin[Q_RAISE] = S.m_r;
+            unsigned int upd = 0;
+            if (P.consume[0]) { upd = P.num_updated[0]; P.num_updated[0] = 0; }
+            P.ctr->updated = upd;
+            P.ctr->tile_visits += (unsigned long long)ntl;
+            P.ctr->raise_visits += (unsigned long long)ntl / 2;
+            P.ctr->tile_iters += S.sweeps / 16;
+            P.ctr->elem_evals += 16ull * S.sweeps;
+            if (done) P.ctr->expanded = (unsigned long long)S.expanded;
+            if (J.debug & 2) {   // diagnostics: the end check's inputs, readable through ufm_debug_lmax
+                int nd0 = 0, nd1 = 0, m0 = INFBITS, m1 = INFBITS;
+                for (int i = 0; i < ntl; ++i) { if (S.dprio[0][i] != INFBITS) { ++nd0; m0 = min(m0, S.dprio[0][i]); } if (S.dprio[1][i] != INFBITS) { ++nd1; m1 = min(m1, S.dprio[1][i]); } }
+                int *d = P.lmax;
+                d[0] = __float_as_int(B); d[1] = __float_as_int(S.B0); d[2] = __float_as_int(S.rbound); d[3] = S.m_r; d[4] = S.m_l;
+                d[5] = nr; d[6] = nl; d[7] = npr; d[8] = npl; d[9] = S.done; d[10] = S.giveup; d[11] = (int)S.sweeps; d[12] = S.expanded;
+                d[13] = nd0; d[14] = m0; d[15] = nd1; d[16] = m1; d[17] = S.any_start_in;
+                for (int i = 0; i < 4; ++i) d[18 + i] = S.soff[i] >= 0 ? __float_as_int(Gs[S.soff[i]]) : -1;
+                for (int i = 0; i < 8; ++i) d[22 + i] = S.dbg[i];
+                S.tstamp[6] = wall_clock64();
+                for (int i = 1; i < 7; ++i) d[30 + i] = (int)(S.tstamp[i] - S.tstamp[0]);
+            }
+        }
+        __syncthreads();
+    }
+    // not done: the launch chain takes over; the tiles changed here join the step's touched list with their values
+    // as of the start of the step (num_nodes_expanded is counted against that snapshot at the end of the step)
+    if (!S.done) {
+#pragma unroll
+        for (int it = 0; it < PER; ++it) {
+            const int i = tid + it * NTHR;
+            if (i >= ntl * TT) continue;
+            const int tl = i / TT, e = i - tl * TT;
+            if (!S.tflag[tl]) continue;
+            const int gt = (J.tx0 + tl / J.nty) * P.TY + J.ty0 + tl % J.nty;
+            P.Gprev[(size_t)gt * TT + e] = init[it];
+            if (e == 0) {
+                P.fresh[gt] = 0;
+                if (atomicAdd(&P.touched[gt], 1) == 0) P.tlist[atomicAdd(&P.ctr->tcount, 1)] = gt;
+            }
+        }
+    }
+    __threadfence();
+    __syncthreads();
+    const int *src = reinterpret_cast<const int *>(P.ctr);
+    int *dst = reinterpret_cast<int *>(host);
+    for (int i = tid; i < (int)(sizeof(DevCounters) / sizeof(int)); i += NTHR)
+        dst[i] = __hip_atomic_load(&src[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __threadfence_system();
+    __syncthreads();
+    if (tid == 0) __hip_atomic_store(flag, J.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
