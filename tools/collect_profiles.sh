@@ -3,7 +3,7 @@
 # (FETCH_SIZE, WRITE_SIZE: MI355X_MICROARCH.md, rocprofv3 PMC slots) of the bench command and of
 # the counter calibration program.  Writes summaries under gpurun_out/profiles_<tag>/.
 set -e
-TAG=${1:-r1}
+TAG=${1:-r2}
 OUT=gpurun_out/profiles_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT

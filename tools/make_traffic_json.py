@@ -46,6 +46,7 @@ out = {
     "other_instantiations": {
         "k_relax<0, 0, false> (lowering, short queues: replans)": kernel("k_relax<0, 0, false>"),
         "k_relax<0, 1, false> (invalidation, replans)": kernel("k_relax<0, 1, false>"),
+        "k_replan_region<0> (block-resident replan: both phases of a replan in one workgroup)": kernel("k_replan_region<0>"),
     },
 }
 out.update(main)

@@ -179,8 +179,9 @@ struct DevParams {
     int *park;                  // [2 queues][2][NT] parked tiles (list + scratch for compaction)
     int *pflag;                 // [2 queues][NT] tile is in the park list
     int *pprio;                 // [2 queues][NT] its priority (float bits)
-    int *queued;                // [2 queues][2][NT] tile is in the candidate list of that launch parity
-    int *prio;                  // [2 queues][2][NT] float bits: smallest value that entered the tile since its last visit
+    int *queued;                // [2 queues][2][NT] launch index + 1 the tile was last queued for (list of that launch parity)
+    unsigned long long *prio;   // [2 queues][2][NT] {tag of the launch it is queued for, float bits}: smallest value that entered the tile
+                                // since its last visit (prio_key / prio_read); entries of earlier launches are stale by their tag, nobody resets them
     int *start;                 // [nmaps][4] start elements (linear index in the map, -1 unused)
     float *bnd;                 // [nmaps] k_start_bound output
     DevDyn *dyn;                // heuristic multiplier, occupancy threshold, focused flag (see DevDyn)
@@ -210,13 +211,26 @@ struct DevParams {
 __device__ __forceinline__ int launch_index(const DevParams &P, int qz, int k_arg) {
     return k_arg >= 0 ? k_arg : P.ctr->kbase[qz] + (-1 - k_arg);
 }
-// queue tile gt in queue qz for the launch that reads list `lst` / priority parity `par`
+// Priorities carry the launch they were queued for in their upper half -- newer launches compare smaller, so an
+// atomicMin of a fresh key always beats what an earlier launch left in the word, and a reader that finds another
+// launch's tag knows the word is stale.  Nothing ever has to be reset between launches, and during launch k nobody
+// writes the words of launch k: every workgroup that scans the list sees the same priorities.
+__device__ __forceinline__ unsigned long long prio_key(int kk, int pbits) {
+    return ((unsigned long long)(unsigned int)(0x7FFFFFFF - kk) << 32) | (unsigned int)pbits;
+}
+__device__ __forceinline__ int prio_read(const DevParams &P, int qz, int kk, int gt) {
+    const unsigned long long v = P.prio[(size_t)(qz * 2 + (kk & 1)) * P.NT + gt];
+    return (int)(v >> 32) == 0x7FFFFFFF - kk ? (int)(unsigned int)v : INFBITS;
+}
+// queue tile gt in queue qz for launch kk (list kk % 3, priority words of parity kk & 1)
 // (`banded` = false for an entry that is only parked beyond the start's key: it must not hold the
 // ordering band of the other entries -- of other maps in a batch -- down)
-__device__ __forceinline__ void activate(const DevParams &P, int qz, int lst, int par, int gt, int pbits, bool banded = true) {
-    atomicMin(&P.prio[(qz * 2 + par) * P.NT + gt], pbits);
+__device__ __forceinline__ void activate(const DevParams &P, int qz, int kk, int gt, int pbits, bool banded = true) {
+    const int lst = kk % 3;
+    const size_t w = (size_t)(qz * 2 + (kk & 1)) * P.NT + gt;
+    atomicMin(&P.prio[w], prio_key(kk, pbits));
     if (banded) atomicMin(&P.ctr->lmin[qz][lst], pbits);
-    if (atomicExch(&P.queued[(qz * 2 + par) * P.NT + gt], 1) == 0) {
+    if (atomicExch(&P.queued[w], kk + 1) != kk + 1) {
         const int k = atomicAdd(&P.ctr->cnt[qz][lst], 1);
         P.cand[(qz * 3 + lst) * P.NT + k] = gt;
     }
@@ -534,7 +548,7 @@ __global__ __launch_bounds__(NTHR, UFM_RELAX_WAVES) void k_relax(DevParams P, in
     const bool io_on = tid < T * T;
     constexpr int Q = (MODE == MODE_LOWER) ? Q_LOWER : Q_RAISE;
     const int k = launch_index(P, Q, k_arg);
-    const int r = k % 3, rn = (k + 1) % 3, rz = (k + 2) % 3, pc = k & 1, pn = pc ^ 1;
+    const int r = k % 3, rz = (k + 2) % 3;
     const int n_long = DYN ? P.ctr->nready[k & 1] : 0;
     const int n = DYN ? n_long + P.ctr->nshort[k & 1] : P.ctr->cnt[Q][r];
     if (blockIdx.x == 0 && tid == 0) {
@@ -546,8 +560,6 @@ __global__ __launch_bounds__(NTHR, UFM_RELAX_WAVES) void k_relax(DevParams P, in
     const int focused = P.dyn->focused, thr = P.dyn->thr;
     UFM_TICK(tkb);
     const int *cand = P.cand + (size_t)(Q * 3 + r) * P.NT;
-    int *prio = P.prio + (size_t)(Q * 2 + pc) * P.NT;
-    int *queued = P.queued + (size_t)(Q * 2 + pc) * P.NT;
     constexpr int CROWS = is_dfm<ALGO> ? T : T + 1;
     constexpr int COFF = is_dfm<ALGO> ? 0 : 1;
 
@@ -555,14 +567,14 @@ __global__ __launch_bounds__(NTHR, UFM_RELAX_WAVES) void k_relax(DevParams P, in
     // the list -> priority loads of the scan below are issued before the start keys are waited for: the two
     // chains of dependent loads (start elements -> G, list -> priority) run side by side instead of in series
     int c_first = 0, pb_first = INFBITS;
-    if (!DYN && MODE == MODE_LOWER && tid < n) { c_first = cand[tid]; pb_first = prio[c_first]; }
+    if (!DYN && MODE == MODE_LOWER && tid < n) { c_first = cand[tid]; pb_first = prio_read(P, Q, k, c_first); }
     if (!DYN && tid < 64) s_B[tid] = (MODE == MODE_LOWER && focused && tid < P.nmaps) ? start_bound(P, tid) : INFINITY;
     __syncthreads();
     if (!DYN && MODE == MODE_LOWER) {   // smallest priority among the entries that are not parked beyond their map's start key
         // (invalidation is order-free -- delta = +inf --: no band, no scan, two dependent loads less per launch)
         int lmin = INFBITS;
         for (int i = tid; i < n; i += NTHR) {
-            const int c = (i == tid) ? c_first : cand[i], pb = (i == tid) ? pb_first : prio[c], mm = c / P.NTm;
+            const int c = (i == tid) ? c_first : cand[i], pb = (i == tid) ? pb_first : prio_read(P, Q, k, c), mm = c / P.NTm;
             const float Bm = mm < 64 ? s_B[mm] : INFINITY;
             if (__int_as_float(pb) < Bm || Bm == INFINITY) lmin = min(lmin, pb);
         }
@@ -604,7 +616,7 @@ __global__ __launch_bounds__(NTHR, UFM_RELAX_WAVES) void k_relax(DevParams P, in
         }
         UFM_TICK(tk0);
         const int gt = DYN ? (i < n_long ? P.ready[i] : P.ready[P.NT - 1 - (i - n_long)]) : cand[i];
-        const int pbits = DYN ? 0 : prio[gt];
+        const int pbits = DYN ? 0 : prio_read(P, Q, k, gt);
         const int m = gt / P.NTm, t = gt - m * P.NTm;
         // lowering: release within the ordering band and below the start's key (end condition);
         // invalidation: release below the bound the host derived from the start's key
@@ -620,12 +632,11 @@ __global__ __launch_bounds__(NTHR, UFM_RELAX_WAVES) void k_relax(DevParams P, in
             } else {
                 release = !(__int_as_float(pbits) > (rbound < 0.0f ? P.ctr->rbound : rbound));
             }
-            __syncthreads();                               // everyone holds pbits; LDS of the previous tile is free
-            if (tid == 0) { queued[gt] = 0; prio[gt] = INFBITS; }
+            __syncthreads();                               // LDS of the previous tile is free
             if (!release) {                                // not yet: carry over / park beyond the bound
                 if (tid == 0) {
                     if (parked || MODE == MODE_RAISE) park_tile(P, Q, gt, pbits);
-                    else activate(P, Q, rn, pn, gt, pbits);
+                    else activate(P, Q, k + 1, gt, pbits);
                 }
                 continue;
             }
@@ -883,7 +894,7 @@ __global__ __launch_bounds__(NTHR, UFM_RELAX_WAVES) void k_relax(DevParams P, in
         if (tid < 9) {
             const int dr = tid / 3 - 1, dc = tid % 3 - 1;
             if (tid == 4) {
-                if (!conv || s_bmin[4] != INFBITS) activate(P, Q, rn, pn, gt, min(s_bmin[4], INFBITS - 1));   // sweep cap hit / border rose: come back
+                if (!conv || s_bmin[4] != INFBITS) activate(P, Q, k + 1, gt, min(s_bmin[4], INFBITS - 1));   // sweep cap hit / border rose: come back
                 P.hint[gt] = s_misc[3];
                 // statistics: summed in this thread's registers, flushed once when the workgroup is done
                 // (same-address atomics from 256 CUs are memory-side operations; five per visit add up)
@@ -893,7 +904,7 @@ __global__ __launch_bounds__(NTHR, UFM_RELAX_WAVES) void k_relax(DevParams P, in
                 st_evals += 16ull * (unsigned long long)s_misc[2];
             } else if (s_bmin[tid] != INFBITS) {
                 const int ntx = tx + dr, nty = ty + dc;
-                if (ntx >= 0 && ntx < P.TX && nty >= 0 && nty < P.TY) activate(P, Q, rn, pn, m * P.NTm + ntx * P.TY + nty, s_bmin[tid]);
+                if (ntx >= 0 && ntx < P.TX && nty >= 0 && nty < P.TY) activate(P, Q, k + 1, m * P.NTm + ntx * P.TY + nty, s_bmin[tid]);
             }
         }
 #ifdef UFM_TIMING
@@ -938,8 +949,6 @@ __global__ void k_triage(DevParams P, int k, float delta, float rbound) {
     const int r = k % 3, rn = (k + 1) % 3, pc = k & 1, pn = pc ^ 1;
     const int n = P.ctr->cnt[Q][r];
     const int *cand = P.cand + (size_t)(Q * 3 + r) * P.NT;
-    int *prio = P.prio + (size_t)(Q * 2 + pc) * P.NT;
-    int *queued = P.queued + (size_t)(Q * 2 + pc) * P.NT;
     const float theta = __int_as_float(P.ctr->lmin[Q][r]) + delta;
     const float rb = (rbound < 0.0f) ? P.ctr->rbound : rbound;
     // start keys of the first 64 maps once per workgroup: their loads (start elements -> G) then run
@@ -956,7 +965,7 @@ __global__ void k_triage(DevParams P, int k, float delta, float rbound) {
         const int i = base + threadIdx.x;
         const bool valid = i < n;
         const int gt = valid ? cand[i] : 0;
-        const int pbits = valid ? prio[gt] : INFBITS;
+        const int pbits = valid ? prio_read(P, Q, k, gt) : INFBITS;
         const int m = gt / P.NTm, t = gt - m * P.NTm;
         bool release = false, parked = false;
         if (valid) {
@@ -968,8 +977,6 @@ __global__ void k_triage(DevParams P, int k, float delta, float rbound) {
             } else {
                 release = !(__int_as_float(pbits) > rb);
             }
-            queued[gt] = 0;
-            prio[gt] = INFBITS;
         }
         // a launch lasts (work per CU) + (its longest visit) when long visits are handed out last;
         // tiles a front is still crossing (first visit of the step, or many sweeps last time) go first
@@ -1001,8 +1008,8 @@ __global__ void k_triage(DevParams P, int k, float delta, float rbound) {
         if (wmin != INFBITS && (threadIdx.x & 63) == 0) atomicMin(&P.ctr->lmin[Q][rn], wmin);
         bool first = false;
         if (carry) {
-            atomicMin(&P.prio[(size_t)(Q * 2 + pn) * P.NT + gt], pbits);
-            first = atomicExch(&P.queued[(size_t)(Q * 2 + pn) * P.NT + gt], 1) == 0;
+            atomicMin(&P.prio[(size_t)(Q * 2 + pn) * P.NT + gt], prio_key(k + 1, pbits));
+            first = atomicExch(&P.queued[(size_t)(Q * 2 + pn) * P.NT + gt], k + 2) != k + 2;
         }
         const int sc = wave_slot(first, &P.ctr->cnt[Q][rn]);
         if (first) P.cand[(size_t)(Q * 3 + rn) * P.NT + sc] = gt;
@@ -1097,7 +1104,7 @@ __device__ void seeds_to_active(const DevParams &P, int qz, int k, int &s_keep) 
     const int n = P.ctr->scount;
     for (int i = threadIdx.x; i < n; i += blockDim.x) {
         const int gt = P.slist[i];
-        if (P.consume[gt / P.NTm]) { P.sflag[gt] = 0; activate(P, qz, k % 3, k & 1, gt, 0); }
+        if (P.consume[gt / P.NTm]) { P.sflag[gt] = 0; activate(P, qz, k, gt, 0); }
         else P.slist2[atomicAdd(&s_keep, 1)] = gt;
     }
     __syncthreads();
@@ -1111,10 +1118,10 @@ __global__ void k_seeds_to_active(DevParams P, int qz, int k) {
 }
 __global__ void k_touched_to_active(DevParams P, int qz, int k) {
     const int n = P.ctr->tcount;
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) activate(P, qz, k % 3, k & 1, P.tlist[i], 0);
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) activate(P, qz, k, P.tlist[i], 0);
 }
 __global__ void k_activate_list(DevParams P, int qz, int k, const int *tiles, int n) {
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) activate(P, qz, k % 3, k & 1, tiles[i], 0);
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) activate(P, qz, k, tiles[i], 0);
 }
 // Phase start: parked tiles whose priority is now inside the bound go back to the candidate list
 // of launch k; the others stay parked.  One workgroup.
@@ -1136,7 +1143,7 @@ __device__ void unpark(const DevParams &P, int qz, int k, float rbound, int &s_k
         } else {
             in = !(__int_as_float(pbits) > rb);
         }
-        if (in) { P.pflag[qz * P.NT + gt] = 0; P.pprio[qz * P.NT + gt] = INFBITS; activate(P, qz, k % 3, k & 1, gt, pbits); }
+        if (in) { P.pflag[qz * P.NT + gt] = 0; P.pprio[qz * P.NT + gt] = INFBITS; activate(P, qz, k, gt, pbits); }
         else tmp[atomicAdd(&s_keep, 1)] = gt;
     }
     __syncthreads();
@@ -1156,7 +1163,7 @@ __global__ void k_queue_min(DevParams P, int qz, int k) {
     const int n = P.ctr->cnt[qz][k % 3];
     int lmin = INFBITS;
     for (int i = threadIdx.x; i < n; i += blockDim.x)
-        lmin = min(lmin, P.prio[(size_t)(qz * 2 + (k & 1)) * P.NT + P.cand[(size_t)(qz * 3 + k % 3) * P.NT + i]]);
+        lmin = min(lmin, prio_read(P, qz, k, P.cand[(size_t)(qz * 3 + k % 3) * P.NT + i]));
     {
         const int np = P.ctr->npark[qz];
         for (int i = threadIdx.x; i < np; i += blockDim.x) lmin = min(lmin, P.pprio[qz * P.NT + P.park[(size_t)(qz * 2) * P.NT + i]]);
@@ -1200,7 +1207,7 @@ __device__ int replan_check(const DevParams &P, int kr, int kl, float margin, bo
     const int n = P.ctr->cnt[Q_RAISE][kr % 3];
     int lmin = INFBITS;
     for (int i = threadIdx.x; i < n; i += blockDim.x)
-        lmin = min(lmin, P.prio[(size_t)(Q_RAISE * 2 + (kr & 1)) * P.NT + P.cand[(size_t)(Q_RAISE * 3 + kr % 3) * P.NT + i]]);
+        lmin = min(lmin, prio_read(P, Q_RAISE, kr, P.cand[(size_t)(Q_RAISE * 3 + kr % 3) * P.NT + i]));
     {   // ... and the parked invalidations
         const int np = P.ctr->npark[Q_RAISE];
         for (int i = threadIdx.x; i < np; i += blockDim.x) lmin = min(lmin, P.pprio[Q_RAISE * P.NT + P.park[(size_t)(Q_RAISE * 2) * P.NT + i]]);
@@ -1395,7 +1402,7 @@ __global__ __launch_bounds__(1024) void k_raise_to_lower(DevParams P, int k_lowe
     __shared__ int s_keep;
     k_lower = launch_index(P, Q_LOWER, k_lower);
     const int n = P.ctr->tcount;
-    for (int i = threadIdx.x; i < n; i += blockDim.x) activate(P, Q_LOWER, k_lower % 3, k_lower & 1, P.tlist[i], 0);
+    for (int i = threadIdx.x; i < n; i += blockDim.x) activate(P, Q_LOWER, k_lower, P.tlist[i], 0);
     unpark(P, Q_LOWER, k_lower, INFINITY, s_keep);
 }
 
@@ -1569,7 +1576,7 @@ int Engine::alloc(int width, int length) {
     dmalloc(P.pflag, sizeof(int) * 2 * P.NT);
     dmalloc(P.pprio, sizeof(int) * 2 * P.NT);
     dmalloc(P.queued, sizeof(int) * 4 * P.NT);
-    dmalloc(P.prio, sizeof(int) * 4 * P.NT);
+    dmalloc(P.prio, sizeof(unsigned long long) * 4 * P.NT);
     dmalloc(P.start, sizeof(int) * 4 * nmaps);
     dmalloc(P.bnd, sizeof(float) * nmaps);
     dmalloc(P.dyn, sizeof(DevDyn));
@@ -1617,7 +1624,7 @@ int Engine::alloc(int width, int length) {
 // drop every queued tile (full re-initialisation: nothing of the old search survives)
 int Engine::reset_queues() {
     HIPCHK(hipMemsetAsync(P.queued, 0, sizeof(int) * 4 * P.NT, stream));
-    k_fill<<<64, 256, 0, stream>>>(reinterpret_cast<float *>(P.prio), (size_t)4 * P.NT, INFINITY);
+    HIPCHK(hipMemsetAsync(P.prio, 0xFF, sizeof(unsigned long long) * 4 * P.NT, stream));   // tag of no launch, larger than any key
     HIPCHK(hipMemsetAsync(P.pflag, 0, sizeof(int) * 2 * P.NT, stream));
     k_fill<<<64, 256, 0, stream>>>(reinterpret_cast<float *>(P.pprio), (size_t)2 * P.NT, INFINITY);
     // the queue state at the head of DevCounters: cnt, rel, lmin, npark, nready, rcursor, nshort, last_work, fin_blocks

@@ -40,6 +40,12 @@ struct RegionJob {
     float delta;                          // width of the ordering band of the lowering sub-rounds (cost units; +inf: no ordering)
 };
 
+// a priority this very kernel may have written (agent-scope load: past the CU's L1)
+__device__ __forceinline__ int prio_read_fresh(const DevParams &P, int qz, int kk, int gt) {
+    const unsigned long long v = __hip_atomic_load(&P.prio[(size_t)(qz * 2 + (kk & 1)) * P.NT + gt], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return (int)(v >> 32) == 0x7FFFFFFF - kk ? (int)(unsigned int)v : INFBITS;
+}
+
 // counters the block kernel shares between its phases (LDS)
 struct RegionShared {
     int wake[16][RWW];                    // per wave: patches with new inputs
@@ -291,7 +297,7 @@ __global__ __launch_bounds__(NTHR) void k_replan_region(DevParams P, RegionJob J
             const int gt = P.slist[i];
             const int tx = gt / P.TY, ty = gt - tx * P.TY;
             P.sflag[gt] = 0;
-            if (tx < J.tx0 || tx >= J.tx0 + J.ntx || ty < J.ty0 || ty >= J.ty0 + J.nty) activate(P, Q_RAISE, J.rb.k_raise % 3, J.rb.k_raise & 1, gt, 0);
+            if (tx < J.tx0 || tx >= J.tx0 + J.ntx || ty < J.ty0 || ty >= J.ty0 + J.nty) activate(P, Q_RAISE, J.rb.k_raise, gt, 0);
         }
         __syncthreads();
         if (tid == 0) {
@@ -509,8 +515,8 @@ __global__ __launch_bounds__(NTHR) void k_replan_region(DevParams P, RegionJob J
         const int tx = J.tx0 + ti, ty = J.ty0 + tj;
         if (tx < 0 || ty < 0 || tx >= P.TX || ty >= P.TY) continue;
         const int gt = tx * P.TY + ty;
-        if (S.actR[i] != INFBITS) activate(P, Q_RAISE, J.rb.k_raise % 3, J.rb.k_raise & 1, gt, S.actR[i]);
-        if (S.actL[i] != INFBITS) activate(P, Q_LOWER, J.k_lower % 3, J.k_lower & 1, gt, S.actL[i]);
+        if (S.actR[i] != INFBITS) activate(P, Q_RAISE, J.rb.k_raise, gt, S.actR[i]);
+        if (S.actL[i] != INFBITS) activate(P, Q_LOWER, J.k_lower, gt, S.actL[i]);
     }
     for (int tl = tid; tl < ntl; tl += NTHR) {
         const int gt = (J.tx0 + tl / J.nty) * P.TY + J.ty0 + tl % J.nty;
@@ -524,8 +530,8 @@ __global__ __launch_bounds__(NTHR) void k_replan_region(DevParams P, RegionJob J
             const int pr = (r / RPW) * 4 + (w >> 2), pc = (r % RPW) * 4 + (w & 3);
             if (pr >= J.ntx * TP || pc >= J.nty * TP) continue;
             const int gt = (J.tx0 + pr / TP) * P.TY + J.ty0 + pc / TP;
-            activate(P, Q_RAISE, J.rb.k_raise % 3, J.rb.k_raise & 1, gt, 0);      // invalidation first, then (k_touched_to_active) lowering
-            activate(P, Q_LOWER, J.k_lower % 3, J.k_lower & 1, gt, 0);
+            activate(P, Q_RAISE, J.rb.k_raise, gt, 0);      // invalidation first, then (k_touched_to_active) lowering
+            activate(P, Q_LOWER, J.k_lower, gt, 0);
         }
     }
     __threadfence();
@@ -541,7 +547,7 @@ __global__ __launch_bounds__(NTHR) void k_replan_region(DevParams P, RegionJob J
         const int nr = __hip_atomic_load(&P.ctr->cnt[Q_RAISE][J.rb.k_raise % 3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         for (int i = tid; i < nr; i += NTHR) {
             const int gt = __hip_atomic_load(&P.cand[(size_t)(Q_RAISE * 3 + J.rb.k_raise % 3) * P.NT + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            mr = min(mr, __hip_atomic_load(&P.prio[(size_t)(Q_RAISE * 2 + (J.rb.k_raise & 1)) * P.NT + gt], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+            mr = min(mr, prio_read_fresh(P, Q_RAISE, J.rb.k_raise, gt));
         }
         const int npr = __hip_atomic_load(&P.ctr->npark[Q_RAISE], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         for (int i = tid; i < npr; i += NTHR) {
@@ -556,7 +562,7 @@ __global__ __launch_bounds__(NTHR) void k_replan_region(DevParams P, RegionJob J
         const int nl = __hip_atomic_load(&P.ctr->cnt[Q_LOWER][J.k_lower % 3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         for (int i = tid; i < nl; i += NTHR) {
             const int gt = __hip_atomic_load(&P.cand[(size_t)(Q_LOWER * 3 + J.k_lower % 3) * P.NT + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            kl = fminf(kl, lower_key(gt, __hip_atomic_load(&P.prio[(size_t)(Q_LOWER * 2 + (J.k_lower & 1)) * P.NT + gt], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)));
+            kl = fminf(kl, lower_key(gt, prio_read_fresh(P, Q_LOWER, J.k_lower, gt)));
         }
         const int npl = __hip_atomic_load(&P.ctr->npark[Q_LOWER], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         for (int i = tid; i < npl; i += NTHR) {
