@@ -56,6 +56,9 @@ constexpr int NTHR = 1024;     // 16 waves; four lanes per node, each wave owns 
 #ifndef UFM_CAUSAL_FILTER
 #define UFM_CAUSAL_FILTER 1    // do not wake a neighbour tile that a changed border value cannot influence
 #endif
+#ifndef UFM_STEP_FILTER
+#define UFM_STEP_FILTER 1        // do not wake a neighbour tile whose border is less than one step above this tile's (see k_relax write-back)
+#endif
 #ifndef UFM_DFM_LAX_VISITS
 #define UFM_DFM_LAX_VISITS 16     // DFM: after this many visits of a tile in one step a 1-ulp rise is rounding noise
 #endif
@@ -883,6 +886,36 @@ __global__ __launch_bounds__(NTHR, UFM_RELAX_WAVES) void k_relax(DevParams P, in
                     need_c = lo < fmaxf(fmaxf(Gs[rl * GP + hc], Gs[(io_r + 1) * GP + hc]), Gs[rh * GP + hc]);
                 }
                 if (er && ec) need_d = lo < Gs[(io_r + 1 + er) * GP + io_c + 1 + ec];
+                // Node planners, lowered value: sharper.  Whatever a neighbour's border node h can gain from this side
+                // comes over the row of cells between the two tiles, from the border nodes next to h: its new value
+                // would be at least (the smallest of those nodes) + (the cheaper of the two cells it touches on this side)
+                // x (one edge length).  (The nodes next to h in the halo belong to a third tile; if one of them is being
+                // lowered in this very launch, this tile sees its old value -- but then it is that tile's visit that
+                // holds the edge's cheaper end and makes the same test with the right number.)  A neighbour whose border already lies below that -- a front running beside
+                // this tile, a step ahead of it -- has nothing to gain and is not woken (41 % of the plan's tile visits
+                // found nothing to do with the test above alone).  Rises keep the test above: an ulp-level correction
+                // must reach whoever was computed from the old value.
+                if (UFM_STEP_FILTER && !is_dfm<ALGO> && gf < gl0) {
+                    const int crow_r = (er < 0) ? 0 : T;                   // cost row / column of the cells between the tiles
+                    const int ccol_c = (ec < 0) ? 0 : T;
+                    auto gain_r = [&](int hc) {                           // h = halo row, LDS column hc (node column hc - 1 of the tile)
+                        const float *mine = Gs + (io_r + 1) * GP;          // my border row (new values)
+                        const float m3 = fminf(fminf(mine[hc - 1], mine[hc]), mine[hc + 1]);       // (halo columns included: a node of the tile beside
+                                                                                           //  this one can be the cheaper end of the edge)
+                        const float c2 = fminf(Cs[crow_r * CP + hc - 1], Cs[crow_r * CP + hc]);
+                        return Gs[(io_r + 1 + er) * GP + hc] > m3 + c2;
+                    };
+                    auto gain_c = [&](int hr) {
+                        const int mc = io_c + 1;
+                        const float m3 = fminf(fminf(Gs[(hr - 1) * GP + mc], Gs[hr * GP + mc]), Gs[(hr + 1) * GP + mc]);
+                        const float c2 = fminf(Cs[(hr - 1) * CP + ccol_c], Cs[hr * CP + ccol_c]);
+                        return Gs[hr * GP + mc + ec] > m3 + c2;
+                    };
+                    if (er && need_r) need_r = gain_r(cl) | gain_r(io_c + 1) | gain_r(ch);
+                    if (ec && need_c) need_c = gain_c(rl) | gain_c(io_r + 1) | gain_c(rh);
+                    if (er && ec && need_d) need_d = Gs[(io_r + 1 + er) * GP + io_c + 1 + ec] >
+                                                      fminf(gf, fminf(Gs[(io_r + 1 + er) * GP + io_c + 1], Gs[(io_r + 1) * GP + io_c + 1 + ec])) + Cs[crow_r * CP + ccol_c];
+                }
                 if ((er || ec) && significant && gf > gl0) atomicMin(&s_bmin[4], __float_as_int(gl0));
             }
             if (!conv) atomicMin(&s_bmin[4], pb);
