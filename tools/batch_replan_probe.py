@@ -8,11 +8,14 @@ ap.add_argument("--size", type=int, default=2048)
 ap.add_argument("--maps", type=int, default=8)
 ap.add_argument("--algo", default="DFM")
 ap.add_argument("--patches", type=int, default=30)
+ap.add_argument("--param", action="append", default=[], help="name=value for ufm_batch_set_param")
 a = ap.parse_args()
 algo = {"FD": 0, "SG": 1, "DFM": 2}[a.algo]
 n, size = a.maps, a.size
 b = ufm_amd.BatchPlanner(n, algo, 1 if algo != 1 else 2)
 b.set_occupancy_threshold(1)
+for kv in a.param:
+    b.set_param(kv.split('=')[0], float(kv.split('=')[1]))
 start, goal = ufm_amd.synth.start_goal(size, size)
 scripts = []
 for i in range(n):
@@ -26,6 +29,7 @@ for k in range(a.patches):
         b.patch_map(i, patch, top, left); b.set_start(i, *s)
     assert b.step() == 0
     cells += b.stats.expanded
+    if os.environ.get('VERBOSE'): print(k, b.stats.launches, b.stats.region_replans_done, b.stats.region_replans)
 t2 = time.perf_counter()
-print("%s %d x %d^2: plan %.1f ms; %d batch replans %.2f ms each (%d launches per step, %.0f cells per step)" % (
-    a.algo, n, size, (t1 - t0) * 1e3, a.patches, (t2 - t1) * 1e3 / a.patches, b.stats.launches, cells / a.patches))
+print("%s %d x %d^2: plan %.1f ms; %d batch replans %.2f ms each (%d launches in the last step, %.0f cells per step); block kernel finished %d of %d map replans alone" % (
+    a.algo, n, size, (t1 - t0) * 1e3, a.patches, (t2 - t1) * 1e3 / a.patches, b.stats.launches, cells / a.patches, b.stats.region_replans_done, b.stats.region_replans))

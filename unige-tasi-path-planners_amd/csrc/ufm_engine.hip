@@ -153,7 +153,7 @@ struct DevCounters {
     float rbound;               // invalidation bound computed on the device (k_prepare_bound / k_check)
     int done;                   // k_check: both queues drained below the start's key
     unsigned int updated;       // k_check: num_nodes_updated summed over the consuming maps
-    int pad2;
+    int done_fail;              // batch replan round in the block kernel: maps whose workgroup could not finish the replan alone
     unsigned long long raise_visits;   // tile visits of the invalidation kernel (subset of tile_visits)
 };
 
@@ -911,8 +911,8 @@ __global__ __launch_bounds__(NTHR, UFM_RELAX_WAVES) void k_relax(DevParams P, in
                         const float c2 = fminf(Cs[(hr - 1) * CP + ccol_c], Cs[hr * CP + ccol_c]);
                         return Gs[hr * GP + mc + ec] > m3 + c2;
                     };
-                    if (er && need_r) need_r = gain_r(cl) | gain_r(io_c + 1) | gain_r(ch);
-                    if (ec && need_c) need_c = gain_c(rl) | gain_c(io_r + 1) | gain_c(rh);
+                    if (er && need_r) need_r = gain_r(cl) || gain_r(io_c + 1) || gain_r(ch);
+                    if (ec && need_c) need_c = gain_c(rl) || gain_c(io_r + 1) || gain_c(rh);
                     if (er && ec && need_d) need_d = Gs[(io_r + 1 + er) * GP + io_c + 1 + ec] >
                                                       fminf(gf, fminf(Gs[(io_r + 1 + er) * GP + io_c + 1], Gs[(io_r + 1) * GP + io_c + 1 + ec])) + Cs[crow_r * CP + ccol_c];
                 }
@@ -1517,6 +1517,7 @@ struct Engine {
     size_t path_cap = 0;                              // floats per buffer
     std::vector<MapState> maps;
     std::vector<PatchRect> pending;
+    std::vector<PatchRect> region_rects;   // the rectangles the current step consumes (jobs of the block kernel)
     int iter[2] = {0, 0};            // index k of the next relax launch of each queue (never reset: the queues persist)
     bool focused = true;             // stop at the start's key like the reference (end_condition)
     bool dynamic_mode = true;        // long queues: k_triage + cursor hand-out
@@ -2040,9 +2041,11 @@ int Engine::step(ufm_stats *out) {
         if (!single) HIPCHK(hipMemcpyAsync(P.consume, consume, sizeof(int) * nmaps, hipMemcpyHostToDevice, stream));
         // consume pending patch rectangles of the participating maps
         std::vector<PatchRect> keep;
+        region_rects.clear();
         for (const PatchRect &r : pending) {
             if (!consume[r.m]) { keep.push_back(r); continue; }
             have_seeds = true;
+            region_rects.push_back(r);
             const int cnt = (r.h + 1) * (r.w + 1);
             if (fused) { int *q = rb.rect[rb.nrect++]; q[0] = r.m; q[1] = r.x; q[2] = r.y; q[3] = r.w; q[4] = r.h; }
             else k_clear_marks<<<(cnt + 255) / 256, 256, 0, stream>>>(P, r.m, r.x, r.y, r.w, r.h);
@@ -2063,45 +2066,82 @@ int Engine::step(ufm_stats *out) {
         if (profiling) while (ev.size() < 4) { hipEvent_t a; HIPCHK(hipEventCreate(&a)); ev.push_back(a); }
         // The block around the patches (ufm_region.h): its goal-side edge `region_ahead` tiles beyond the patches' centre,
         // the rest of its extent behind it -- where the elements that lean on the patched cells are.
-        RegionJob rj{};
+        RegionJobs rjs{};
         bool regioned = false;
-        if (fused && use_region && rb.nrect > 0) {
+        {
             const bool nodes = algo != UFM_ALGO_DFM;
-            int ex0 = INT32_MAX, ex1 = -1, ey0 = INT32_MAX, ey1 = -1;
-            for (int r = 0; r < rb.nrect; ++r) {
-                const int *qr = rb.rect[r];
-                ex0 = std::min(ex0, qr[1]); ex1 = std::max(ex1, qr[1] + qr[4] - (nodes ? 0 : 1));
-                ey0 = std::min(ey0, qr[2]); ey1 = std::max(ey1, qr[2] + qr[3] - (nodes ? 0 : 1));
-            }
-            auto place = [&](int e0, int e1, int goal_e, int ntiles_map, int *t0, int *nt) {
-                *nt = std::min(std::min(region_tiles, RTMAX), ntiles_map);
-                const int tc = ((e0 + e1) / 2) / T;
-                int lo = (goal_e >= (e0 + e1) / 2) ? tc + region_ahead - *nt + 1 : tc - region_ahead;
-                lo = std::max(0, std::min(lo, ntiles_map - *nt));
-                *t0 = lo;
-                return e0 / T >= lo && e1 / T <= lo + *nt - 1;      // every consumed rectangle inside the block
+            // the block of one map: around its consumed rectangles; false if they do not fit into one block
+            auto place_job = [&](RegionJob &j, const ReplanBegin &b, int m) {
+                if (b.nrect <= 0) return false;
+                int ex0 = INT32_MAX, ex1 = -1, ey0 = INT32_MAX, ey1 = -1;
+                for (int r = 0; r < b.nrect; ++r) {
+                    const int *qr = b.rect[r];
+                    ex0 = std::min(ex0, qr[1]); ex1 = std::max(ex1, qr[1] + qr[4] - (nodes ? 0 : 1));
+                    ey0 = std::min(ey0, qr[2]); ey1 = std::max(ey1, qr[2] + qr[3] - (nodes ? 0 : 1));
+                }
+                auto place = [&](int e0, int e1, int goal_e, int ntiles_map, int *t0, int *nt) {
+                    *nt = std::min(std::min(region_tiles, RTMAX), ntiles_map);
+                    const int tc = ((e0 + e1) / 2) / T;
+                    int lo = (goal_e >= (e0 + e1) / 2) ? tc + region_ahead - *nt + 1 : tc - region_ahead;
+                    lo = std::max(0, std::min(lo, ntiles_map - *nt));
+                    *t0 = lo;
+                    return e0 / T >= lo && e1 / T <= lo + *nt - 1;      // every consumed rectangle inside the block
+                };
+                const bool okx = place(ex0, ex1, maps[m].goal_ex, P.TX, &j.tx0, &j.ntx);
+                const bool oky = place(ey0, ey1, maps[m].goal_ey, P.TY, &j.ty0, &j.nty);
+                if (!(okx && oky)) return false;
+                j.rb = b; j.rb.k_raise = iter[Q_RAISE]; j.rb.band = band;
+                j.dyn = dyn_now; j.k_lower = iter[Q_LOWER]; j.max_sweeps = region_sweeps; j.debug = region_debug;
+                j.slack = 255.0f * SQRT2F + 1.0f;     // the largest cost of one move (a diagonal through the most expensive cell)
+                j.delta = region_band > 0.0f ? region_band * 4.0f * mean_cost : INFINITY;
+                j.map = m;
+                return true;
             };
-            const bool okx = place(ex0, ex1, maps[0].goal_ex, P.TX, &rj.tx0, &rj.ntx);
-            const bool oky = place(ey0, ey1, maps[0].goal_ey, P.TY, &rj.ty0, &rj.nty);
-            regioned = okx && oky;
+            if (fused && use_region) {                       // one map, a few small patches
+                regioned = place_job(rjs.j[0], rb, 0);
+                rjs.n = 1; rjs.j[0].batch = 0;
+            } else if (!single && use_region && spin_wait && nmaps <= RJOBS && !region_rects.empty()) {
+                // a batch: one job per consuming map, every one of them with 1..4 small rectangles of its own
+                bool ok = true;
+                rjs.n = 0;
+                const int *st_el = h_scratch + 5 * nmaps + 4;
+                const float *sp = reinterpret_cast<const float *>(h_scratch + 9 * nmaps + 8);
+                for (int m = 0; m < nmaps && ok; ++m) {
+                    if (!consume[m]) continue;
+                    ReplanBegin b{};
+                    for (const PatchRect &r : region_rects) {
+                        if (r.m != m) continue;
+                        if (b.nrect >= 4 || (r.w + 1) * (r.h + 1) > 65 * 65) { ok = false; break; }
+                        int *q = b.rect[b.nrect++]; q[0] = r.m; q[1] = r.x; q[2] = r.y; q[3] = r.w; q[4] = r.h;
+                    }
+                    for (int i = 0; i < 4; ++i) b.sb.start[i] = st_el[4 * m + i];
+                    b.sb.consume = 1; b.sb.sx = sp[2 * m]; b.sb.sy = sp[2 * m + 1];
+                    RegionJob &j = rjs.j[rjs.n];
+                    ok = ok && place_job(j, b, m);
+                    j.batch = 1;
+                    ++rjs.n;
+                }
+                regioned = ok && rjs.n > 0;
+            }
         }
         const bool graphed = !regioned && fused && use_graph && nr < 250 && nl < 250;
         if (regioned) {
-            rb.k_raise = iter[Q_RAISE]; rb.band = band;
-            rj.rb = rb; rj.dyn = dyn_now; rj.k_lower = iter[Q_LOWER]; rj.seq = ++pub_seq; rj.max_sweeps = region_sweeps; rj.debug = region_debug;
-            rj.slack = 255.0f * SQRT2F + 1.0f;     // the largest cost of one move (a diagonal through the most expensive cell)
-            rj.delta = region_band > 0.0f ? region_band * 4.0f * mean_cost : INFINITY;
+            const unsigned int seq = ++pub_seq;
+            for (int i = 0; i < rjs.n; ++i) rjs.j[i].seq = seq;
+            if (rjs.j[0].batch)     // the counters the maps' workgroups add to
+                HIPCHK(hipMemsetAsync(&P.ctr->rbound, 0, offsetof(DevCounters, done_fail) + sizeof(int) - offsetof(DevCounters, rbound), stream));
             dyn_dev = dyn_now; dyn_pending = false;
-            if (algo == UFM_ALGO_FD) k_replan_region<UFM_ALGO_FD><<<1, NTHR, 0, stream>>>(P, rj, h_ctr, h_flag);
-            else if (algo == UFM_ALGO_SG) k_replan_region<UFM_ALGO_SG><<<1, NTHR, 0, stream>>>(P, rj, h_ctr, h_flag);
-            else if (opt_lvl == 0) k_replan_region<UFM_ALGO_DFM><<<1, NTHR, 0, stream>>>(P, rj, h_ctr, h_flag);
-            else k_replan_region<ALGO_DFM1><<<1, NTHR, 0, stream>>>(P, rj, h_ctr, h_flag);
+            const dim3 g(rjs.n), b(NTHR);
+            if (algo == UFM_ALGO_FD) k_replan_region<UFM_ALGO_FD><<<g, b, 0, stream>>>(P, rjs, h_ctr, h_flag);
+            else if (algo == UFM_ALGO_SG) k_replan_region<UFM_ALGO_SG><<<g, b, 0, stream>>>(P, rjs, h_ctr, h_flag);
+            else if (opt_lvl == 0) k_replan_region<UFM_ALGO_DFM><<<g, b, 0, stream>>>(P, rjs, h_ctr, h_flag);
+            else k_replan_region<ALGO_DFM1><<<g, b, 0, stream>>>(P, rjs, h_ctr, h_flag);
             HIPCHK(hipGetLastError());
             last_active = 1;
             int rc = wait_published();
             if (rc != UFM_OK) return rc;
-            ++region_runs;
-            if (h_ctr->done) ++region_done;
+            region_runs += (uint32_t)rjs.n;
+            if (h_ctr->done) region_done += (uint32_t)rjs.n;
         } else if (graphed) {
             rb.k_raise = iter[Q_RAISE]; rb.band = band;
             hipGraphExec_t ge = nullptr;

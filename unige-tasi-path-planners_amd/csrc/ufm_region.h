@@ -38,7 +38,13 @@ struct RegionJob {
                                           // counts and a phase timeline go to the diagnostics array (ufm_debug_lmax, tools/replan_timeline.py)
     float slack;                          // lowering results up to this far beyond the start's key are still applied (see Bgate)
     float delta;                          // width of the ordering band of the lowering sub-rounds (cost units; +inf: no ordering)
+    int map;                              // the map of a batch this job belongs to
+    int batch;                            // part of a batch step: the host has done the step bookkeeping, the last workgroup publishes
 };
+// A replan round of a batch (BASELINE config 4: every map of the GPU's share gets its own patch): one workgroup per
+// map, all in one launch.
+constexpr int RJOBS = 8;
+struct RegionJobs { int n; RegionJob j[RJOBS]; };
 
 // a priority this very kernel may have written (agent-scope load: past the CU's L1)
 __device__ __forceinline__ int prio_read_fresh(const DevParams &P, int qz, int kk, int gt) {
@@ -126,7 +132,7 @@ __device__ void region_phase(const DevParams &P, const RegionJob &J, float *Gs, 
         if (dc < 0) wake_sel &= 0x000F000F000F000Full; else if (dc > 0) wake_sel &= 0xF000F000F000F000ull;
     }
     const int colour = ((nd >> 2) & 1) | ((nd & 1) << 1);
-    const float sx = P.spos[0], sy = P.spos[1];
+    const float sx = J.rb.sb.sx, sy = J.rb.sb.sy;
     const int rx0 = J.tx0 * T, ry0 = J.ty0 * T;
     long long budget = J.max_sweeps;
     unsigned long long my_sweeps = 0;
@@ -266,20 +272,23 @@ __device__ void region_phase(const DevParams &P, const RegionJob &J, float *Gs, 
 }
 
 template <int ALGO>
-__global__ __launch_bounds__(NTHR) void k_replan_region(DevParams P, RegionJob J, DevCounters *host, unsigned int *flag) {
+__global__ __launch_bounds__(NTHR) void k_replan_region(DevParams P, RegionJobs JS, DevCounters *host, unsigned int *flag) {
     __shared__ float Gs[(RN + 2) * RP];
     __shared__ uint8_t Cb[(RN + 1) * RCP];
     __shared__ RegionShared S;
+    __shared__ int s_last;
     constexpr bool CELLS = is_dfm<ALGO>;
     constexpr int COFF = CELLS ? 0 : 1;
     const int tid = threadIdx.x;
+    const RegionJob &J = JS.j[blockIdx.x];
+    const int m = J.map, gt0 = m * P.NTm;                     // the job's map and its first tile
     const int ntl = J.ntx * J.nty;
     const int rx0 = J.tx0 * T, ry0 = J.ty0 * T, rnx = J.ntx * T, rny = J.nty * T;
 
     const unsigned long long t_begin = wall_clock64();
     // ---- 0. what k_replan_begin does: step bookkeeping, mark reset, the seeds, the invalidation bound ----
-    if (tid == 0) *P.dyn = J.dyn;
-    step_begin(P, J.rb.sb);
+    if (tid == 0 && blockIdx.x == 0) *P.dyn = J.dyn;
+    if (!J.batch) step_begin(P, J.rb.sb);
     for (int r = 0; r < J.rb.nrect; ++r) {
         const int *qr = J.rb.rect[r];
         for (int e = tid; e < (qr[3] + 1) * (qr[4] + 1); e += NTHR) clear_mark(P, qr[0], qr[1], qr[2], qr[3], qr[4], e);
@@ -291,21 +300,21 @@ __global__ __launch_bounds__(NTHR) void k_replan_region(DevParams P, RegionJob J
     if (tid == 0) S.rmin = INFBITS;
     const float hm = J.dyn.hm;
     const int thr = J.dyn.thr, focused = J.dyn.focused;
-    {   // pending seeds (single map, all consumed): tiles inside the block are handled here, any other goes to the queue
+    {   // pending seeds of this map (all consumed): tiles inside the block are handled here, any other goes to the queue
         const int n = P.ctr->scount;
         for (int i = tid; i < n; i += NTHR) {
             const int gt = P.slist[i];
-            const int tx = gt / P.TY, ty = gt - tx * P.TY;
+            if (gt / P.NTm != m) continue;
+            const int tx = (gt - gt0) / P.TY, ty = (gt - gt0) - tx * P.TY;
             P.sflag[gt] = 0;
             if (tx < J.tx0 || tx >= J.tx0 + J.ntx || ty < J.ty0 || ty >= J.ty0 + J.nty) activate(P, Q_RAISE, J.rb.k_raise, gt, 0);
         }
         __syncthreads();
         if (tid == 0) {
-            P.ctr->scount = 0;
-            const float b0 = start_bound(P, 0);            // the start's key before the patch (step_begin stored the start)
+            if (!J.batch) { P.ctr->scount = 0; P.ctr->done = 0; }   // (a batch: the last workgroup, when everybody has read the list)
+            const float b0 = start_bound(P, m);            // the start's key before the patch (the step's start is in place)
             S.B0 = b0;
             S.rbound = focused ? b0 + J.rb.band : INFINITY;
-            P.ctr->done = 0;
             bool in = false;
             for (int i = 0; i < 4; ++i) {
                 const int e = J.rb.sb.start[i];
@@ -323,7 +332,7 @@ __global__ __launch_bounds__(NTHR) void k_replan_region(DevParams P, RegionJob J
     // ---- 1. stage the block: tiles (contiguous 1 KB each), the 1-element frame around it, the cost bytes ----
     for (int i = tid; i < ntl * TT; i += NTHR) {
         const int tl = i / TT, e = i - tl * TT, ti = tl / J.nty, tj = tl - ti * J.nty;
-        const int gt = (J.tx0 + ti) * P.TY + J.ty0 + tj;
+        const int gt = gt0 + (J.tx0 + ti) * P.TY + J.ty0 + tj;
         Gs[(ti * T + e / T + 1) * RP + tj * T + e % T + 1] = P.G[(size_t)gt * TT + e];
     }
     for (int i = tid; i < 2 * (rny + 2) + 2 * rnx; i += NTHR) {
@@ -334,14 +343,14 @@ __global__ __launch_bounds__(NTHR) void k_replan_region(DevParams P, RegionJob J
         else { hx = i - 2 * (rny + 2) - rnx; hy = rny; }
         const int x = rx0 + hx, y = ry0 + hy;
         const bool in = x >= 0 && y >= 0 && x < P.TX * T && y < P.TY * T;
-        Gs[(hx + 1) * RP + hy + 1] = in ? P.G[gaddr(P, 0, x, y)] : INFINITY;
+        Gs[(hx + 1) * RP + hy + 1] = in ? P.G[gaddr(P, m, x, y)] : INFINITY;
     }
     {
         const int crow = rnx + COFF, ccol = rny + COFF;
         for (int i = tid; i < crow * ccol; i += NTHR) {
             const int r = i / ccol, c = i - r * ccol;
             const int cx = rx0 + r - COFF, cy = ry0 + c - COFF;
-            Cb[r * RCP + c] = (cx >= 0 && cy >= 0 && cx < P.L && cy < P.W) ? P.cost[(size_t)cx * P.W + cy] : (uint8_t)255;
+            Cb[r * RCP + c] = (cx >= 0 && cy >= 0 && cx < P.L && cy < P.W) ? P.cost[(size_t)m * P.cstride + (size_t)cx * P.W + cy] : (uint8_t)255;
         }
     }
     // the seeds: every patch that holds an element of a consumed rectangle (a superset of the changed cells' elements;
@@ -362,7 +371,7 @@ __global__ __launch_bounds__(NTHR) void k_replan_region(DevParams P, RegionJob J
     if (tid == 0) S.tstamp[2] = wall_clock64();
     if (tid < 4) S.swas[tid] = (S.soff[tid] >= 0 && Gs[S.soff[tid]] < INFINITY) ? 1 : 0;
     __syncthreads();
-    const int goal_lx = P.goal[0] - rx0, goal_ly = P.goal[1] - ry0;
+    const int goal_lx = P.goal[2 * m] - rx0, goal_ly = P.goal[2 * m + 1] - ry0;
 
     // ---- 2. invalidate, lower; again while an invalidation that was held back lies below the start's new key ----
     for (int round = 0;; ++round) {
@@ -458,7 +467,7 @@ __global__ __launch_bounds__(NTHR) void k_replan_region(DevParams P, RegionJob J
         if (i >= ntl * TT) continue;
         const int tl = i / TT, e = i - tl * TT, ti = tl / J.nty, tj = tl - ti * J.nty;
         if (!S.tflag[tl]) continue;                                         // nothing was applied in this tile
-        const int tx = J.tx0 + ti, ty = J.ty0 + tj, gt = tx * P.TY + ty;
+        const int tx = J.tx0 + ti, ty = J.ty0 + tj, gt = gt0 + tx * P.TY + ty;
         const int io_r = e / T, io_c = e % T;
         const float gl0 = P.G[(size_t)gt * TT + e];
         const float gf = Gs[(ti * T + io_r + 1) * RP + tj * T + io_c + 1];
@@ -514,12 +523,12 @@ __global__ __launch_bounds__(NTHR) void k_replan_region(DevParams P, RegionJob J
         else { ti = i - 2 * (J.nty + 2) - J.ntx; tj = J.nty; }
         const int tx = J.tx0 + ti, ty = J.ty0 + tj;
         if (tx < 0 || ty < 0 || tx >= P.TX || ty >= P.TY) continue;
-        const int gt = tx * P.TY + ty;
+        const int gt = gt0 + tx * P.TY + ty;
         if (S.actR[i] != INFBITS) activate(P, Q_RAISE, J.rb.k_raise, gt, S.actR[i]);
         if (S.actL[i] != INFBITS) activate(P, Q_LOWER, J.k_lower, gt, S.actL[i]);
     }
     for (int tl = tid; tl < ntl; tl += NTHR) {
-        const int gt = (J.tx0 + tl / J.nty) * P.TY + J.ty0 + tl % J.nty;
+        const int gt = gt0 + (J.tx0 + tl / J.nty) * P.TY + J.ty0 + tl % J.nty;
         if (S.dprio[0][tl] != INFBITS) park_tile(P, Q_LOWER, gt, S.dprio[0][tl]);
         if (S.dprio[1][tl] != INFBITS) park_tile(P, Q_RAISE, gt, S.dprio[1][tl]);
     }
@@ -529,7 +538,7 @@ __global__ __launch_bounds__(NTHR) void k_replan_region(DevParams P, RegionJob J
             if (!(S.wake[w][r >> 5] & (1 << (r & 31)))) continue;
             const int pr = (r / RPW) * 4 + (w >> 2), pc = (r % RPW) * 4 + (w & 3);
             if (pr >= J.ntx * TP || pc >= J.nty * TP) continue;
-            const int gt = (J.tx0 + pr / TP) * P.TY + J.ty0 + pc / TP;
+            const int gt = gt0 + (J.tx0 + pr / TP) * P.TY + J.ty0 + pc / TP;
             activate(P, Q_RAISE, J.rb.k_raise, gt, 0);      // invalidation first, then (k_touched_to_active) lowering
             activate(P, Q_LOWER, J.k_lower, gt, 0);
         }
@@ -547,16 +556,16 @@ __global__ __launch_bounds__(NTHR) void k_replan_region(DevParams P, RegionJob J
         const int nr = __hip_atomic_load(&P.ctr->cnt[Q_RAISE][J.rb.k_raise % 3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         for (int i = tid; i < nr; i += NTHR) {
             const int gt = __hip_atomic_load(&P.cand[(size_t)(Q_RAISE * 3 + J.rb.k_raise % 3) * P.NT + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            mr = min(mr, prio_read_fresh(P, Q_RAISE, J.rb.k_raise, gt));
+            if (gt / P.NTm == m) mr = min(mr, prio_read_fresh(P, Q_RAISE, J.rb.k_raise, gt));
         }
         const int npr = __hip_atomic_load(&P.ctr->npark[Q_RAISE], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         for (int i = tid; i < npr; i += NTHR) {
             const int gt = __hip_atomic_load(&P.park[(size_t)(Q_RAISE * 2) * P.NT + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            mr = min(mr, __hip_atomic_load(&P.pprio[Q_RAISE * P.NT + gt], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+            if (gt / P.NTm == m) mr = min(mr, __hip_atomic_load(&P.pprio[Q_RAISE * P.NT + gt], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
         }
         auto lower_key = [&](int gt, int pbits) {      // smallest key an element of the tile can have: priority + hm * dist(start, tile)
-            if (pbits == INFBITS) return INFINITY;
-            return __int_as_float(pbits) + (focused ? tile_heuristic(P, 0, gt / P.TY, gt % P.TY) : 0.0f);
+            if (pbits == INFBITS || gt / P.NTm != m) return INFINITY;
+            return __int_as_float(pbits) + (focused ? tile_heuristic(P, m, (gt - gt0) / P.TY, (gt - gt0) % P.TY) : 0.0f);
         };
         float kl = INFINITY;
         const int nl = __hip_atomic_load(&P.ctr->cnt[Q_LOWER][J.k_lower % 3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -576,20 +585,32 @@ __global__ __launch_bounds__(NTHR) void k_replan_region(DevParams P, RegionJob J
         if (tid == 0) {
             bool done;
             if (focused && B < INFINITY) done = !(__int_as_float(S.m_r) < B) && !(__int_as_float(S.m_l) < B);
-            else done = (nr == 0 && nl == 0 && (focused ? (S.m_r == INFBITS && S.m_l == INFBITS) : true));
+            else done = (S.m_r == INFBITS && S.m_l == INFBITS) && (J.batch || (nr == 0 && nl == 0));   // (a batch: the other maps'
+            //                                           workgroups add to the same lists meanwhile; this map's entries are what counts)
             if (S.giveup) done = false;
             S.done = done ? 1 : 0;
-            P.ctr->done = S.done;
-            P.ctr->rbound = S.rbound;
-            P.ctr->qmin[Q_RAISE] = S.m_r;
             unsigned int upd = 0;
-            if (P.consume[0]) { upd = P.num_updated[0]; P.num_updated[0] = 0; }
-            P.ctr->updated = upd;
-            P.ctr->tile_visits += (unsigned long long)ntl;
-            P.ctr->raise_visits += (unsigned long long)ntl / 2;
-            P.ctr->tile_iters += S.sweeps / 16;
-            P.ctr->elem_evals += 16ull * S.sweeps;
-            if (done) P.ctr->expanded = (unsigned long long)S.expanded;
+            if (P.consume[m]) { upd = P.num_updated[m]; P.num_updated[m] = 0; }
+            if (!J.batch) {
+                P.ctr->done = S.done;
+                P.ctr->rbound = S.rbound;
+                P.ctr->qmin[Q_RAISE] = S.m_r;
+                P.ctr->updated = upd;
+                P.ctr->tile_visits += (unsigned long long)ntl;
+                P.ctr->raise_visits += (unsigned long long)ntl / 2;
+                P.ctr->tile_iters += S.sweeps / 16;
+                P.ctr->elem_evals += 16ull * S.sweeps;
+                if (done) P.ctr->expanded = (unsigned long long)S.expanded;
+            } else {           // shared counters (the host zeroed them for the step); the last workgroup draws the conclusion
+                if (!done) atomicAdd(&P.ctr->done_fail, 1);
+                atomicMax(reinterpret_cast<int *>(&P.ctr->rbound), __float_as_int(S.rbound));   // (positive floats order like their bits)
+                atomicAdd(&P.ctr->updated, upd);
+                atomicAdd(&P.ctr->tile_visits, (unsigned long long)ntl);
+                atomicAdd(&P.ctr->raise_visits, (unsigned long long)ntl / 2);
+                atomicAdd(&P.ctr->tile_iters, S.sweeps / 16);
+                atomicAdd(&P.ctr->elem_evals, 16ull * S.sweeps);
+                if (done) atomicAdd(&P.ctr->expanded, (unsigned long long)S.expanded);
+            }
             if (J.debug & 2) {   // diagnostics: the end check's inputs, readable through ufm_debug_lmax
                 int nd0 = 0, nd1 = 0, m0 = INFBITS, m1 = INFBITS;
                 for (int i = 0; i < ntl; ++i) { if (S.dprio[0][i] != INFBITS) { ++nd0; m0 = min(m0, S.dprio[0][i]); } if (S.dprio[1][i] != INFBITS) { ++nd1; m1 = min(m1, S.dprio[1][i]); } }
@@ -614,7 +635,7 @@ __global__ __launch_bounds__(NTHR) void k_replan_region(DevParams P, RegionJob J
             if (i >= ntl * TT) continue;
             const int tl = i / TT, e = i - tl * TT;
             if (!S.tflag[tl]) continue;
-            const int gt = (J.tx0 + tl / J.nty) * P.TY + J.ty0 + tl % J.nty;
+            const int gt = gt0 + (J.tx0 + tl / J.nty) * P.TY + J.ty0 + tl % J.nty;
             P.Gprev[(size_t)gt * TT + e] = init[it];
             if (e == 0) {
                 P.fresh[gt] = 0;
@@ -624,6 +645,19 @@ __global__ __launch_bounds__(NTHR) void k_replan_region(DevParams P, RegionJob J
     }
     __threadfence();
     __syncthreads();
+    if (J.batch) {             // the last workgroup to get here publishes for all of them
+        if (tid == 0) s_last = (atomicAdd(&P.ctr->fin_blocks, 1) == (int)gridDim.x - 1);
+        __syncthreads();
+        if (!s_last) return;
+        __threadfence();
+        if (tid == 0) {
+            P.ctr->fin_blocks = 0;
+            P.ctr->scount = 0;
+            P.ctr->done = __hip_atomic_load(&P.ctr->done_fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0 ? 1 : 0;
+        }
+        __threadfence();
+        __syncthreads();
+    }
     const int *src = reinterpret_cast<const int *>(P.ctr);
     int *dst = reinterpret_cast<int *>(host);
     for (int i = tid; i < (int)(sizeof(DevCounters) / sizeof(int)); i += NTHR)
