@@ -139,7 +139,8 @@ def launch_ranks(n):
         if code != 0 and rc == 0:
             rc = code
             print("bench.py: rank %d exited with code %d" % (r, code), file=sys.stderr)
-    sys.stdout.write(out0 or "")
+    for line in (out0 or "").splitlines():      # the contract is ONE JSON line on stdout; whatever else rank 0 printed goes to stderr
+        print(line, file=sys.stdout if line.startswith("{") else sys.stderr)
     sys.stdout.flush()
     return rc
 
