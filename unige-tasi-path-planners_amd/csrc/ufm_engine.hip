@@ -964,16 +964,6 @@ __global__ __launch_bounds__(NTHR, UFM_RELAX_WAVES) void k_relax(DevParams P, in
     }
 }
 
-// index for the lanes with `pred` from one atomicAdd per wave (all lanes of the wave must call)
-__device__ __forceinline__ int wave_slot(bool pred, int *counter) {
-    const unsigned long long mk = __ballot(pred);
-    if (!mk) return 0;
-    const int lane = threadIdx.x & 63, leader = __ffsll((long long)mk) - 1;
-    int base = 0;
-    if (lane == leader) base = atomicAdd(counter, __popcll(mk));
-    base = __shfl(base, leader);
-    return base + __popcll(mk & ((1ull << lane) - 1ull));
-}
 // Vectorised triage for long queues: one thread per queued tile decides "release now" (append to
 // the ready list of the following relax launch) or "carry over" (same list ring as k_relax).
 template <int MODE>
@@ -1020,31 +1010,41 @@ __global__ void k_triage(DevParams P, int k, float delta, float rbound) {
             P.rank[gt] = (int)fminf(255.0f, fmaxf(0.0f, 255.0f * (__int_as_float(pbits) - lo) / fmaxf(delta, 1e-6f)));
         }
 #endif
-        const int sl = wave_slot(lng, &P.ctr->nready[k & 1]);
-        if (lng) P.ready[sl] = gt;
+        // What an entry becomes -- released (long / short), parked, carried -- is decided above; the words that say whether
+        // a park / carry is the tile's first are swapped next, all of them in flight together; then the four list cursors
+        // are advanced by ONE instruction (lanes 0..3, one cursor each, the counts from ballots) instead of four returning
+        // atomics one after the other: this kernel is a chain of dependent memory round trips, once per band step of a plan.
         const bool sht = release && !lng;
-        const int ss = wave_slot(sht, &P.ctr->nshort[k & 1]);
-        if (sht) P.ready[P.NT - 1 - ss] = gt;
-        // beyond the bound: park (park_tile, aggregated)
         const bool prk = valid && !release && (parked || MODE == MODE_RAISE);
-        bool fresh = false;
+        const bool carry = valid && !release && !prk;
+        bool fresh = false, first = false;
         if (prk) {
             atomicMin(&P.pprio[Q * P.NT + gt], pbits);
             fresh = atomicExch(&P.pflag[Q * P.NT + gt], 1) == 0;
         }
-        const int sp = wave_slot(fresh, &P.ctr->npark[Q]);
-        if (fresh) P.park[(size_t)(Q * 2) * P.NT + sp] = gt;
-        // inside the bound, beyond the band: carry over to the next launch (activate, aggregated)
-        const bool carry = valid && !release && !prk;
+        if (carry) {     // (nobody has queued anything for launch k + 1 yet -- its list fills while launch k runs, after this kernel --
+            //              and a list holds a tile once: every carry is its tile's first entry there, no need to ask)
+            atomicMin(&P.prio[(size_t)(Q * 2 + pn) * P.NT + gt], prio_key(k + 1, pbits));
+            P.queued[(size_t)(Q * 2 + pn) * P.NT + gt] = k + 2;
+            first = true;
+        }
         int wmin = carry ? pbits : INFBITS;
         for (int off = 32; off; off >>= 1) wmin = min(wmin, __shfl_xor(wmin, off));
-        if (wmin != INFBITS && (threadIdx.x & 63) == 0) atomicMin(&P.ctr->lmin[Q][rn], wmin);
-        bool first = false;
-        if (carry) {
-            atomicMin(&P.prio[(size_t)(Q * 2 + pn) * P.NT + gt], prio_key(k + 1, pbits));
-            first = atomicExch(&P.queued[(size_t)(Q * 2 + pn) * P.NT + gt], k + 2) != k + 2;
+        const int lane = threadIdx.x & 63;
+        if (wmin != INFBITS && lane == 0) atomicMin(&P.ctr->lmin[Q][rn], wmin);
+        const unsigned long long m0 = __ballot(lng), m1 = __ballot(sht), m2 = __ballot(fresh), m3 = __ballot(first);
+        int slot0 = 0;
+        if (lane < 4) {
+            const unsigned long long mk = lane == 0 ? m0 : (lane == 1 ? m1 : (lane == 2 ? m2 : m3));
+            int *ctr = lane == 0 ? &P.ctr->nready[k & 1] : (lane == 1 ? &P.ctr->nshort[k & 1] : (lane == 2 ? &P.ctr->npark[Q] : &P.ctr->cnt[Q][rn]));
+            if (mk) slot0 = atomicAdd(ctr, __popcll(mk));
         }
-        const int sc = wave_slot(first, &P.ctr->cnt[Q][rn]);
+        const unsigned long long below = (1ull << lane) - 1ull;
+        const int b0 = __shfl(slot0, 0), b1 = __shfl(slot0, 1), b2 = __shfl(slot0, 2), b3 = __shfl(slot0, 3);
+        if (lng) P.ready[b0 + __popcll(m0 & below)] = gt;
+        if (sht) P.ready[P.NT - 1 - (b1 + __popcll(m1 & below))] = gt;
+        if (fresh) P.park[(size_t)(Q * 2) * P.NT + b2 + __popcll(m2 & below)] = gt;
+        const int sc = b3 + __popcll(m3 & below);
         if (first) P.cand[(size_t)(Q * 3 + rn) * P.NT + sc] = gt;
     }
 }
