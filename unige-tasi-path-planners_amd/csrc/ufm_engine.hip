@@ -552,6 +552,9 @@ __global__ __launch_bounds__(NTHR, UFM_RELAX_WAVES) void k_relax(DevParams P, in
     constexpr int Q = (MODE == MODE_LOWER) ? Q_LOWER : Q_RAISE;
     const int k = launch_index(P, Q, k_arg);
     const int r = k % 3, rz = (k + 2) % 3;
+    // (the ready entry at this workgroup's own index is asked for together with the list lengths: it is the right one
+    //  whenever the index lies in the front part of the list -- almost always -- and a memory round trip earlier)
+    const int spec_first = DYN ? P.ready[blockIdx.x] : 0;
     const int n_long = DYN ? P.ctr->nready[k & 1] : 0;
     const int n = DYN ? n_long + P.ctr->nshort[k & 1] : P.ctr->cnt[Q][r];
     if (blockIdx.x == 0 && tid == 0) {
@@ -618,7 +621,7 @@ __global__ __launch_bounds__(NTHR, UFM_RELAX_WAVES) void k_relax(DevParams P, in
             break;
         }
         UFM_TICK(tk0);
-        const int gt = DYN ? (i < n_long ? P.ready[i] : P.ready[P.NT - 1 - (i - n_long)]) : cand[i];
+        const int gt = DYN ? (i < n_long ? (i == (int)blockIdx.x ? spec_first : P.ready[i]) : P.ready[P.NT - 1 - (i - n_long)]) : cand[i];
         const int pbits = DYN ? 0 : prio_read(P, Q, k, gt);
         const int m = gt / P.NTm, t = gt - m * P.NTm;
         // lowering: release within the ordering band and below the start's key (end condition);
