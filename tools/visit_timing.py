@@ -14,6 +14,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--size", type=int, default=4096)
 ap.add_argument("--algo", default="FD")
 ap.add_argument("--replans", type=int, default=0)
+ap.add_argument("--param", action="append", default=[], help="name=value for ufm_set_param")
 a = ap.parse_args()
 algo = {"FD": (ufm_amd.ALGO_FD, 1), "SG": (ufm_amd.ALGO_SG, 2), "DFM": (ufm_amd.ALGO_DFM, 1)}[a.algo]
 L = ufm_amd.load_library()
@@ -28,6 +29,7 @@ def report(tag, p):
     v = max(d[3], 1)
     print("%s: launches %d kernel_ms %.2f visits %d | per visit: stage %.2f us  sweeps %.2f us  writeback %.2f us  total %.2f us" % (
         tag, p.stats.launches, p.stats.kernel_ms, d[3], d[0] / v / 100, d[1] / v / 100, d[2] / v / 100, (d[0] + d[1] + d[2]) / v / 100))
+    print("   wb timeline of thread 0 (us after the sweeps): decided %.2f committed %.2f stores+filter issued %.2f waited %.2f barrier passed %.2f" % (d[4] / v / 100, d[5] / v / 100, d[6] / v / 100, d[7] / v / 100, d[60] / v / 100))
     print("   visit-time histogram (2 us bins): " + " ".join("%d" % d[8 + i] for i in range(32)))
     print("   per-wave sweep-count histogram:   " + " ".join("%d" % d[40 + i] for i in range(24)))
 
@@ -109,6 +111,8 @@ def wave_report():
 for rep in range(2):
     p = ufm_amd.Planner(*algo)
     p.set_profiling(1)
+    for kv in a.param:
+        p.set_param(kv.split('=')[0], float(kv.split('=')[1]))
     p.set_occupancy_threshold(1)
     p.set_map(cost)
     p.set_start(*start)

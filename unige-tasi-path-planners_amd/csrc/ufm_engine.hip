@@ -155,6 +155,8 @@ struct DevCounters {
     unsigned int updated;       // k_check: num_nodes_updated summed over the consuming maps
     int done_fail;              // batch replan round in the block kernel: maps whose workgroup could not finish the replan alone
     unsigned long long raise_visits;   // tile visits of the invalidation kernel (subset of tile_visits)
+    int own_stops;              // resident kernel: workgroups that left on the time limit instead of on an empty queue
+    int own_pad;
 };
 
 // Per-step scalars the kernels read from memory, not from their by-value parameter block: the replans are
@@ -199,6 +201,12 @@ struct DevParams {
     unsigned int *num_updated;  // [nmaps]
     int *consume;               // [nmaps]
     int *lmax;                  // [LMAX] diagnostics: per launch, the largest per-wave sweep count of any tile
+    int *own_prio;              // [OWN_NW][own_slots] resident lowering kernel (k_relax<.,LOWER,false,true>): the queue, one word per tile, grouped
+                                // by the workgroup that owns the tile -- float bits of its priority, >= INFBITS = not queued (see own_push)
+    int *own_min;               // [OWN_NW] smallest priority each owner holds (queued or in flight): a hint for the ordering band, not exact
+    unsigned long long own_limit;   // wall-clock ticks (100 MHz) after which the resident kernel hands back to the launch chain
+    int own_flags;              // diagnostics: 1 = no tile taken ahead (every visit starts with a fresh look at the queue)
+    int own_slots, own_sx, own_sy;  // words per owner = nmaps * own_sx * own_sy; 16 x 16-tile super-blocks per map side
     DevCounters *ctr;
     int EX, EY;                 // elements per map (nodes or cells)
     int L, W;                   // cells per map
@@ -276,6 +284,52 @@ __device__ __forceinline__ float tile_heuristic(const DevParams &P, int m, int t
     const float x0 = (float)(tx * T), x1 = (float)(tx * T + T - 1), y0 = (float)(ty * T), y1 = (float)(ty * T + T - 1);
     const float dx = fmaxf(fmaxf(x0 - sx, sx - x1), 0.0f), dy = fmaxf(fmaxf(y0 - sy, sy - y1), 0.0f);
     return hm * hypotf(dx, dy) * 0.999f;   // (0.999: stay below the reference's own float rounding of the distance)
+}
+
+// ---- the queue of the resident lowering kernel ---------------------------------------------------------
+// One launch runs a whole lowering phase: OWN_NW workgroups, one per CU, stay resident and each owns the tiles
+// (tx, ty) with (tx mod 16, ty mod 16) = its index -- any stretch of a front is spread over all of them.  A tile's
+// queue entry is ONE word that only its owner ever removes:
+//     key (< INFBITS)  queued with that priority          -- neighbours lower it with atomicMin, fire and forget
+//     OWN_MARK         being visited by its owner         -- an atomicMin of a key re-queues it meanwhile
+//     other >= INFBITS empty (INFBITS + 1 + a per-owner visit count: the word never returns to an earlier empty value)
+// so a tile is never visited twice at once, no list is appended to and no cursor is shared.  The owner resets
+// MARK -> empty only after the activations of that visit have been performed: the words of all owners are non-empty
+// as long as anything is queued, in flight, or about to be queued, and two identical all-empty collects of them in a
+// row mean the phase is over (an empty value never repeats, so identical collects are a true snapshot).
+constexpr int OWN_NW = 256;
+constexpr int OWN_MARK = 0x7FFFFFFF;
+__device__ __forceinline__ void own_locate(const DevParams &P, int gt, int &o, int &s) {
+    const int m = gt / P.NTm, t = gt - m * P.NTm, tx = t / P.TY, ty = t - tx * P.TY;
+    o = ((tx & 15) << 4) | (ty & 15);
+    s = (m * P.own_sx + (tx >> 4)) * P.own_sy + (ty >> 4);
+}
+// tile of slot s of owner o; -1 if that position lies outside the map
+__device__ __forceinline__ int own_tile(const DevParams &P, int o, int s, int &m, int &tx, int &ty) {
+    const int per = P.own_sx * P.own_sy;
+    m = s / per;
+    const int r = s - m * per, bx = r / P.own_sy, by = r - bx * P.own_sy;
+    tx = bx * 16 + (o >> 4); ty = by * 16 + (o & 15);
+    return (tx < P.TX && ty < P.TY) ? m * P.NTm + tx * P.TY + ty : -1;
+}
+__device__ __forceinline__ void own_push(const DevParams &P, int gt, int pbits) {
+    int o, s;
+    own_locate(P, gt, o, s);
+    __hip_atomic_fetch_min(&P.own_prio[(size_t)o * P.own_slots + s], pbits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_fetch_min(&P.own_min[o], pbits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// Values other workgroups write while the resident kernel runs are read and written past the per-XCD L2
+// (agent-scope accesses); the launch-per-band-step kernels rely on the kernel boundaries instead.
+// A workgroup barrier that orders LDS traffic only: __syncthreads() also waits for every global access in flight, which
+// is exactly what the resident kernel's decision -- made while its stores and its prefetches are on their way -- must not do.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+template <bool COH> __device__ __forceinline__ float ld_f(const float *p) {
+    if constexpr (COH) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else return *p;
+}
+template <bool COH> __device__ __forceinline__ void st_f(float *p, float v) {
+    if constexpr (COH) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else *p = v;
 }
 
 // ---- optional in-kernel timing of tile visits (-DUFM_TIMING, diagnostic builds only) -------
@@ -532,8 +586,11 @@ __global__ void k_cost_windows(DevParams P, int m) {
 //     value as priority.
 // DYN: the tiles come from the ready list k_triage built (taken through an atomic cursor: perfect
 // balance, used while the queue is long); !DYN: triage fused as described above (short queues).
-template <int ALGO, int MODE, bool DYN>
+// OWN: the resident form (one launch per lowering phase): no lists at all, every workgroup serves the tiles it owns
+// from their queue words (own_push above) until all of them, everywhere, are empty.
+template <int ALGO, int MODE, bool DYN, bool OWN = false>
 __global__ __launch_bounds__(NTHR, UFM_RELAX_WAVES) void k_relax(DevParams P, int k_arg, float delta, float rbound, int max_sweeps) {
+    static_assert(!OWN || (!DYN && MODE == MODE_LOWER), "the resident kernel lowers");
     __shared__ float Gs[(T + 2) * GP];
     __shared__ float Cs[(T + 1) * CP];
     __shared__ int s_wake[16];  // per wave: bit j = patch j of the wave has new inputs (PPW bits)
@@ -543,6 +600,14 @@ __global__ __launch_bounds__(NTHR, UFM_RELAX_WAVES) void k_relax(DevParams P, in
     __shared__ int s_bmin[9];   // per direction: smallest changed value on that border (float bits)
     __shared__ int s_min;
     __shared__ float s_B[64];   // fused triage: start key of the first 64 maps
+    __shared__ unsigned long long s_best;   // resident kernel: {priority, slot} of the best tile this workgroup may take / collect checksum
+    __shared__ int s_gmin;      // resident kernel: votes of a decision (own_decide), then what thread 0 made of it (1 take, -1 stop)
+    __shared__ int s_pf[OWN ? NTHR : 1];      // resident kernel: this workgroup's first queue words and the other owners' hints as of the
+    __shared__ int s_pfh[OWN ? OWN_NW : 1];   // start of the visit in progress (loaded straight into LDS while it sweeps)
+    __shared__ int s_se[OWN ? 256 : 1];       // resident kernel: start elements of the first 64 maps (index into G, -1 unused) ...
+    __shared__ float s_sh[OWN ? 256 : 1];     // ... and hm * dist(start, element)
+    __shared__ int s_own[4];    // resident kernel, thread 0's book-keeping: 0 slot whose mark is still to be taken back, 1 slot being visited, 2 visits
+    __shared__ unsigned long long s_stat[3];   // thread 4's per-workgroup statistics (visits, sweeps, evaluations), flushed once at the end
 
     const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
     const int q = lane & 3, nd = lane >> 2;                    // quad lane, node within the 4x4 patch
@@ -556,8 +621,8 @@ __global__ __launch_bounds__(NTHR, UFM_RELAX_WAVES) void k_relax(DevParams P, in
     //  whenever the index lies in the front part of the list -- almost always -- and a memory round trip earlier)
     const int spec_first = DYN ? P.ready[blockIdx.x] : 0;
     const int n_long = DYN ? P.ctr->nready[k & 1] : 0;
-    const int n = DYN ? n_long + P.ctr->nshort[k & 1] : P.ctr->cnt[Q][r];
-    if (blockIdx.x == 0 && tid == 0) {
+    const int n = OWN ? 0x7FFFFFFF : (DYN ? n_long + P.ctr->nshort[k & 1] : P.ctr->cnt[Q][r]);
+    if (!OWN && blockIdx.x == 0 && tid == 0) {
         P.ctr->cnt[Q][rz] = 0; P.ctr->rel[Q][rz] = 0; P.ctr->lmin[Q][rz] = INFBITS;
         P.ctr->nready[(k + 1) & 1] = 0; P.ctr->nshort[(k + 1) & 1] = 0; P.ctr->rcursor[(k + 1) & 1] = 0;   // for the next triage
         if (DYN) { P.ctr->rel[Q][r] = n; if (n) P.ctr->last_work[Q] = k; }
@@ -573,10 +638,10 @@ __global__ __launch_bounds__(NTHR, UFM_RELAX_WAVES) void k_relax(DevParams P, in
     // the list -> priority loads of the scan below are issued before the start keys are waited for: the two
     // chains of dependent loads (start elements -> G, list -> priority) run side by side instead of in series
     int c_first = 0, pb_first = INFBITS;
-    if (!DYN && MODE == MODE_LOWER && tid < n) { c_first = cand[tid]; pb_first = prio_read(P, Q, k, c_first); }
-    if (!DYN && tid < 64) s_B[tid] = (MODE == MODE_LOWER && focused && tid < P.nmaps) ? start_bound(P, tid) : INFINITY;
+    if (!DYN && !OWN && MODE == MODE_LOWER && tid < n) { c_first = cand[tid]; pb_first = prio_read(P, Q, k, c_first); }
+    if (!DYN && !OWN && tid < 64) s_B[tid] = (MODE == MODE_LOWER && focused && tid < P.nmaps) ? start_bound(P, tid) : INFINITY;
     __syncthreads();
-    if (!DYN && MODE == MODE_LOWER) {   // smallest priority among the entries that are not parked beyond their map's start key
+    if (!DYN && !OWN && MODE == MODE_LOWER) {   // smallest priority among the entries that are not parked beyond their map's start key
         // (invalidation is order-free -- delta = +inf --: no band, no scan, two dependent loads less per launch)
         int lmin = INFBITS;
         for (int i = tid; i < n; i += NTHR) {
@@ -604,9 +669,125 @@ __global__ __launch_bounds__(NTHR, UFM_RELAX_WAVES) void k_relax(DevParams P, in
     // before the first visit (256 same-address atomics across 8 XCDs take microseconds); the launch
     // has one workgroup per CU, so all of them start at once and the longest-first order is kept.
     bool first_pop = UFM_STATIC_FIRST;
-    unsigned long long st_visits = 0, st_iters = 0, st_evals = 0;   // thread 4's per-workgroup statistics
+    if (tid == 4) { s_stat[0] = 0ull; s_stat[1] = 0ull; s_stat[2] = 0ull; }   // (thread 4 alone reads and writes them)
     int st_lmax = 0;
+    // resident kernel: this workgroup's queue words; own_prev = slot of a finished visit whose "being visited" mark is still
+    // to be taken back; own_next = slot taken (marked) for the next visit while the current one was being written back
+    int *const own_q = OWN ? P.own_prio + (size_t)blockIdx.x * P.own_slots : nullptr;
+    int own_next = -1, own_slot_now = -1;   // (the same in every thread)
+    const unsigned long long own_t0 = OWN ? wall_clock64() : 0ull;
+    if (OWN && tid == 0) { s_own[0] = -1; s_own[1] = -1; s_own[2] = 0; }
+    if constexpr (OWN) {   // the start elements of the first 64 maps: address in G and the heuristic term of their keys (start_bound())
+        const float hm = P.dyn->hm;
+        for (int e = tid; e < 4 * min(P.nmaps, 64); e += NTHR) {
+            const int el = P.start[e], m_ = e >> 2;
+            const int x = el / P.EY, y = el - x * P.EY;
+            s_se[e] = el >= 0 ? (int)gaddr(P, m_, x, y) : -1;
+            s_sh[e] = el >= 0 ? hm * hypotf(P.spos[2 * m_] - (float)x, P.spos[2 * m_ + 1] - (float)y) : 0.0f;
+        }
+    }
+    // The decision: s_best = {priority, slot} of my best queued tile; s_gmin bit 0 = some other owner holds something, bit 1 =
+    // ... something more than an ordering band below my best (which then has to wait).  From this thread's first queue word
+    // and one other owner's hint.  Opens and closes with a barrier.  (No reduction tree, no same-address atomics from whole
+    // waves -- either costs more than a microsecond here: a handful of lanes have a queued word, and the hints only vote.)
+    auto own_decide = [&](int v0, int hint, int skip) {   // skip: the slot of the visit in progress (its turn comes again later)
+        if (tid == 0) { s_best = ~0ull; s_gmin = 0; }
+        lds_barrier();
+        unsigned long long best = ~0ull;
+#pragma unroll 1
+        for (int sl = tid; sl < P.own_slots; sl += NTHR) {
+            const int v = (sl == tid) ? v0 : __hip_atomic_load(&own_q[sl], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (v < INFBITS && sl != skip) best = min(best, ((unsigned long long)(unsigned int)v << 32) | (unsigned int)sl);
+        }
+        if (best != ~0ull) atomicMin(&s_best, best);
+        lds_barrier();
+        const unsigned long long b = s_best;
+        const bool any = hint != INFBITS;
+        const bool below = any && b != ~0ull && __int_as_float((int)(b >> 32)) > __int_as_float(hint) + delta;
+        const unsigned long long ba = __ballot(any), bb = __ballot(below);
+        if (lane == 0 && ba) atomicOr(&s_gmin, bb ? 3 : 1);
+        lds_barrier();
+    };
+    // thread 0, after a decision: take back the mark of the visit before the last (its activations have long been performed),
+    // say what this workgroup holds, mark the chosen tile.  The exchange is not waited for here.
+    auto own_commit = [&](unsigned long long b, bool take, bool wait) -> int {   // wait: that visit's activations have only just been issued
+        const int own_prev = s_own[0];
+        if (own_prev >= 0) {
+            if (wait) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            int expect = OWN_MARK;
+            __hip_atomic_compare_exchange_strong(&own_q[own_prev], &expect, INFBITS + 1 + (s_own[2] & 0x3FFFFF),
+                                                 __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            s_own[0] = -1;
+        }
+        __hip_atomic_store(&P.own_min[blockIdx.x], b != ~0ull ? (int)(b >> 32) : INFBITS, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        int was = INFBITS;
+        if (take) {
+            s_own[2] += 1;
+            was = __hip_atomic_exchange(&own_q[(int)(unsigned int)b], OWN_MARK, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        return was;   // the priority the tile was queued with (on its way: not waited for here)
+    };
     for (int i = blockIdx.x;; i += gridDim.x) {
+        int gt_own = -1;
+        if constexpr (OWN) {
+            if (tid == 0 && s_own[1] >= 0) { s_own[0] = s_own[1]; s_own[1] = -1; }   // (at most one mark waits: own_commit ran since)
+            while (own_next < 0) {                             // nothing was taken ahead: look, wait, look again
+                __syncthreads();                               // LDS of the previous visit / round is free
+                int hint = INFBITS;
+                if (tid < OWN_NW && tid != (int)blockIdx.x) hint = __hip_atomic_load(&P.own_min[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const int v0 = tid < P.own_slots ? __hip_atomic_load(&own_q[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : INFBITS;
+                own_decide(v0, hint, -1);
+                const unsigned long long b = s_best;
+                const int votes = s_gmin;
+                const bool have = b != ~0ull;
+                const bool take = have && !(votes & 2);        // inside the ordering band
+                bool stop = false;
+                if (!have && !(votes & 1)) {
+                    // nobody seems to hold anything: two collects of all queue words; identical and all empty = the phase is over
+                    unsigned long long h0 = 0ull, h1 = 1ull;
+                    bool ok = true;
+                    const int total = OWN_NW * P.own_slots;
+                    for (int pass = 0; pass < 2 && ok; ++pass) {
+                        __syncthreads();
+                        if (tid == 0) s_best = 0ull;
+                        __syncthreads();
+                        unsigned long long acc = 0ull;
+                        bool mine_ok = true;
+#pragma unroll 1
+                        for (int e = tid; e < total; e += NTHR) {
+                            const int v = __hip_atomic_load(&P.own_prio[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            if (v < INFBITS || v == OWN_MARK) mine_ok = false;
+                            acc += ((unsigned long long)(unsigned int)v + 1ull) * (0x9E3779B97F4A7C15ull + 2ull * (unsigned long long)e);
+                        }
+                        for (int o_ = 32; o_; o_ >>= 1) acc += (unsigned long long)__shfl_xor((long long)acc, o_);
+                        if (lane == 0) atomicAdd(&s_best, acc);
+                        ok = __syncthreads_and(mine_ok) != 0;
+                        if (pass == 0) h0 = s_best; else h1 = s_best;
+                    }
+                    stop = ok && h0 == h1;
+                }
+                if (tid == 0) {
+                    int flag = 0;
+                    const bool late = !stop && wall_clock64() - own_t0 > P.own_limit;   // hand back to the launch chain (k_own_export): never stay for ever
+                    if (late) atomicAdd(&P.ctr->own_stops, 1);
+                    s_own[3] = own_commit(b, take && !stop && !late, true);   // (waits for the exchange: the visit's loads must not overtake
+                    if (stop || late) flag = -1;                              //  it -- an activation it removes has to be one whose values
+                    else if (take) flag = 1;                                  //  the visit then sees)
+                    s_gmin = flag;
+                }
+                __syncthreads();
+                const int flag = s_gmin;
+                if (flag > 0) own_next = __builtin_amdgcn_readfirstlane((int)(unsigned int)b);
+                if (flag < 0) break;
+                if (flag == 0) __builtin_amdgcn_s_sleep(32);
+            }
+            if (own_next < 0) break;
+            { int m_, tx_, ty_; gt_own = own_tile(P, blockIdx.x, own_next, m_, tx_, ty_); }
+            if (tid == 0) s_own[1] = own_next;
+            own_slot_now = own_next;
+            own_next = -1;
+            __syncthreads();                                   // LDS of the previous visit is free
+        }
         if (DYN && !first_pop) {                           // next ready tile, whoever is free takes it
             __syncthreads();
             if (tid == 0) s_min = (UFM_STATIC_FIRST ? gridDim.x : 0) + atomicAdd(&P.ctr->rcursor[k & 1], 1);
@@ -621,12 +802,12 @@ __global__ __launch_bounds__(NTHR, UFM_RELAX_WAVES) void k_relax(DevParams P, in
             break;
         }
         UFM_TICK(tk0);
-        const int gt = DYN ? (i < n_long ? (i == (int)blockIdx.x ? spec_first : P.ready[i]) : P.ready[P.NT - 1 - (i - n_long)]) : cand[i];
-        const int pbits = DYN ? 0 : prio_read(P, Q, k, gt);
+        const int gt = OWN ? gt_own : (DYN ? (i < n_long ? (i == (int)blockIdx.x ? spec_first : P.ready[i]) : P.ready[P.NT - 1 - (i - n_long)]) : cand[i]);
+        const int pbits = (DYN || OWN) ? 0 : prio_read(P, Q, k, gt);
         const int m = gt / P.NTm, t = gt - m * P.NTm;
         // lowering: release within the ordering band and below the start's key (end condition);
         // invalidation: release below the bound the host derived from the start's key
-        if (!DYN) {
+        if (!DYN && !OWN) {
             bool release, parked = false;
             if (MODE == MODE_LOWER) {
                 // (the start key as of the beginning of the launch, s_B: re-reading the start elements for
@@ -660,10 +841,13 @@ __global__ __launch_bounds__(NTHR, UFM_RELAX_WAVES) void k_relax(DevParams P, in
         // first waves paid three round trips in series, thread 0's wave up to five.)
         const int ht = tid - (NTHR - (4 * T + 4));               // halo: the last 4T+4 threads of the workgroup
         constexpr int CN = CROWS * CROWS;
-        const float gl0 = Gt[io_on ? tid : 0];
-        const float hv = ring[ht >= 0 ? ht : 0];
+        const float gl0 = ld_f<OWN>(&Gt[io_on ? tid : 0]);
+        const float hv = ld_f<OWN>(&ring[ht >= 0 ? ht : 0]);
         const int c0 = ct[tid < CN ? tid : 0];
         const int goal_x = P.goal[2 * m], goal_y = P.goal[2 * m + 1];   // (with the rest: read after the barrier they cost two more round trips)
+        // resident kernel: the values of the map's start elements, one per lane (for the end condition below)
+        const int own_sa = (OWN && focused && tid < 4 && m < 64) ? s_se[m * 4 + tid] : -1;
+        const float own_sg = own_sa >= 0 ? ld_f<OWN>(&P.G[own_sa]) : INFINITY;
         if (tid == 0) {
             const int seen = atomicAdd(&P.touched[gt], 1);   // visits of this tile in the current step
             const int first = seen == 0;
@@ -671,6 +855,23 @@ __global__ __launch_bounds__(NTHR, UFM_RELAX_WAVES) void k_relax(DevParams P, in
             s_misc[0] = first; s_misc[1] = seen; s_misc[2] = 0; s_misc[3] = 0; s_idle = 0; s_giveup = 0;
         }
         if (tid < 16) s_wake[tid] = (1 << PPW) - 1;
+        if constexpr (OWN) if (focused && w == 0) {
+            // End condition: a tile whose priority lies beyond its map's start key (start_bound(): the largest key among the
+            // start elements that have been reached) is not relaxed -- it goes to the park list of the launch chain, the
+            // counterpart of the entries the reference leaves in its priority queue when end_condition() fires -- and the visit
+            // ends without a sweep (no wake bits).  The start key only falls while a phase lowers: beyond it stays beyond it.
+            float bq = (own_sa >= 0 && own_sg < INFINITY) ? own_sg + s_sh[m * 4 + (tid & 3)] : 0.0f;
+            bq = fmaxf(bq, __shfl_xor(bq, 1));
+            bq = fmaxf(bq, __shfl_xor(bq, 2));
+            if (tid == 0) {
+                const float B = m < 64 ? (bq > 0.0f ? bq : INFINITY) : start_bound(P, m);
+                const int kb = s_own[3];                         // the priority the tile was taken with
+                if (!(__int_as_float(kb) + tile_heuristic(P, m, tx, ty) < B || B == INFINITY)) {
+                    for (int j = 0; j < 16; ++j) s_wake[j] = 0;
+                    park_tile(P, Q_LOWER, gt, kb);
+                }
+            }
+        }
         if (tid >= 32 && tid < 41) s_bmin[tid - 32] = INFBITS;
 
         // the tile (contiguous) and its halo: the ring record, in this order (RING_*)
@@ -703,6 +904,12 @@ __global__ __launch_bounds__(NTHR, UFM_RELAX_WAVES) void k_relax(DevParams P, in
             const int any = __syncthreads_or(io_on && gl0 != INFINITY);
             if (any && io_on) P.Gprev[(size_t)gt * TT + tid] = gl0;
             if (tid == 0) P.fresh[gt] = any ? 0 : 1;
+        }
+        if constexpr (OWN) {   // (no register is held for these: the data lands in LDS some time during the sweeps)
+            typedef __attribute__((address_space(3))) void *lds_ptr;
+            typedef const __attribute__((address_space(1))) void *glb_ptr;
+            __builtin_amdgcn_global_load_lds((glb_ptr)(own_q + min(tid, P.own_slots - 1)), (lds_ptr)(s_pf + (tid & ~63)), 4, 0, 16);              // (16: sc1)
+            if (tid < OWN_NW) __builtin_amdgcn_global_load_lds((glb_ptr)(P.own_min + tid), (lds_ptr)(s_pfh + (tid & ~63)), 4, 0, 16);
         }
 
         // per-lane constants of the wave's four patches
@@ -835,18 +1042,33 @@ __global__ __launch_bounds__(NTHR, UFM_RELAX_WAVES) void k_relax(DevParams P, in
         __syncthreads();
         UFM_TICK(tk2);
 
+        int own_was = INFBITS;
+        if constexpr (OWN) {
+            // The next tile is chosen and marked now, from the queue words as they were when this visit began to sweep: the
+            // exchange is on its way while this visit is written back, and the next visit's loads follow the write-back with no
+            // queue round trip in between.  (A fresh look costs two round trips in a row -- words, then exchange -- per visit.)
+            own_decide(tid < P.own_slots ? s_pf[tid] : INFBITS, (tid < OWN_NW && tid != (int)blockIdx.x) ? s_pfh[tid] : INFBITS, own_slot_now);
+            const unsigned long long b = s_best;
+            const bool take = b != ~0ull && !(s_gmin & 2) && !(P.own_flags & 1);
+            if (tid == 0) own_was = own_commit(b, take, false);
+            own_next = __builtin_amdgcn_readfirstlane(take ? (int)(unsigned int)b : -1);
+        }
         // write back what changed; note which neighbours saw their halo change
-        const float gf = io_on ? Gs[(io_r + 1) * GP + io_c + 1] : gl0;
+        // (this thread's row and column, made opaque once per visit: the compiler otherwise computes the two dozen LDS addresses of
+        //  the tests below ahead of the tile loop and carries them through the sweeps -- registers the sweep loop needs)
+        int wb_r = io_r, wb_c = io_c;
+        asm volatile("" : "+v"(wb_r), "+v"(wb_c));
+        const float gf = io_on ? Gs[(wb_r + 1) * GP + wb_c + 1] : gl0;
         if (gf != gl0) {
-            Gt[tid] = gf;
+            st_f<OWN>(&Gt[tid], gf);
             {   // a border value also lives in the rings of the neighbours it borders
-                const int er_ = (io_r == 0) ? -1 : ((io_r == T - 1) ? 1 : 0);
-                const int ec_ = (io_c == 0) ? -1 : ((io_c == T - 1) ? 1 : 0);
+                const int er_ = (wb_r == 0) ? -1 : ((wb_r == T - 1) ? 1 : 0);
+                const int ec_ = (wb_c == 0) ? -1 : ((wb_c == T - 1) ? 1 : 0);
                 const bool rok = er_ && tx + er_ >= 0 && tx + er_ < P.TX, cok = ec_ && ty + ec_ >= 0 && ty + ec_ < P.TY;
-                if (rok) P.ring[(size_t)(gt + er_ * P.TY) * RING + (er_ < 0 ? RING_BOT : RING_TOP) + io_c] = gf;
-                if (cok) P.ring[(size_t)(gt + ec_) * RING + (ec_ < 0 ? RING_RIGHT : RING_LEFT) + io_r] = gf;
+                if (rok) st_f<OWN>(&P.ring[(size_t)(gt + er_ * P.TY) * RING + (er_ < 0 ? RING_BOT : RING_TOP) + wb_c], gf);
+                if (cok) st_f<OWN>(&P.ring[(size_t)(gt + ec_) * RING + (ec_ < 0 ? RING_RIGHT : RING_LEFT) + wb_r], gf);
                 if (rok && cok)   // my corner (er_, ec_) is the opposite corner of the diagonal neighbour's halo
-                    P.ring[(size_t)(gt + er_ * P.TY + ec_) * RING + RING_CORNER + (er_ < 0 ? 2 : 0) + (ec_ < 0 ? 1 : 0)] = gf;
+                    st_f<OWN>(&P.ring[(size_t)(gt + er_ * P.TY + ec_) * RING + RING_CORNER + (er_ < 0 ? 2 : 0) + (ec_ < 0 ? 1 : 0)], gf);
             }
             // DFM only: the float fixed point of the upwind quadratic is not unique;
             // neighbouring tiles can push each other's border values up one ulp at a time for tens of
@@ -864,8 +1086,8 @@ __global__ __launch_bounds__(NTHR, UFM_RELAX_WAVES) void k_relax(DevParams P, in
             // priority handed to a neighbour: the new value (lowering) / the value that was
             // invalidated (raising: the reference's key of an under-consistent element, min(g,rhs) = g)
             const int pb = __float_as_int((MODE == MODE_LOWER) ? gf : gl0);
-            const int er = (io_r == 0) ? -1 : ((io_r == T - 1) ? 1 : 0);
-            const int ec = (io_c == 0) ? -1 : ((io_c == T - 1) ? 1 : 0);
+            const int er = (wb_r == 0) ? -1 : ((wb_r == T - 1) ? 1 : 0);
+            const int ec = (wb_c == 0) ? -1 : ((wb_c == T - 1) ? 1 : 0);
             // Causality: every value the update operators produce is larger than each input it
             // depends on (the interpolated cost-to-goal of the far edge plus a positive traversal
             // cost), so an element h of a neighbour tile can neither be lowered by nor have been
@@ -878,17 +1100,17 @@ __global__ __launch_bounds__(NTHR, UFM_RELAX_WAVES) void k_relax(DevParams P, in
             bool need_r = true, need_c = true, need_d = true;
             if (UFM_CAUSAL_FILTER && MODE == MODE_LOWER) {
                 const float lo = fminf(gf, gl0);
-                const int cl = max(io_c - 1, 0) + 1, ch = min(io_c + 1, T - 1) + 1;     // halo columns / rows that belong
-                const int rl = max(io_r - 1, 0) + 1, rh = min(io_r + 1, T - 1) + 1;     // to the edge neighbour itself
+                const int cl = max(wb_c - 1, 0) + 1, ch = min(wb_c + 1, T - 1) + 1;     // halo columns / rows that belong
+                const int rl = max(wb_r - 1, 0) + 1, rh = min(wb_r + 1, T - 1) + 1;     // to the edge neighbour itself
                 if (er) {
-                    const float *h = Gs + (io_r + 1 + er) * GP;
-                    need_r = lo < fmaxf(fmaxf(h[cl], h[io_c + 1]), h[ch]);
+                    const float *h = Gs + (wb_r + 1 + er) * GP;
+                    need_r = lo < fmaxf(fmaxf(h[cl], h[wb_c + 1]), h[ch]);
                 }
                 if (ec) {
-                    const int hc = io_c + 1 + ec;
-                    need_c = lo < fmaxf(fmaxf(Gs[rl * GP + hc], Gs[(io_r + 1) * GP + hc]), Gs[rh * GP + hc]);
+                    const int hc = wb_c + 1 + ec;
+                    need_c = lo < fmaxf(fmaxf(Gs[rl * GP + hc], Gs[(wb_r + 1) * GP + hc]), Gs[rh * GP + hc]);
                 }
-                if (er && ec) need_d = lo < Gs[(io_r + 1 + er) * GP + io_c + 1 + ec];
+                if (er && ec) need_d = lo < Gs[(wb_r + 1 + er) * GP + wb_c + 1 + ec];
                 // Node planners, lowered value: sharper.  Whatever a neighbour's border node h can gain from this side
                 // comes over the row of cells between the two tiles, from the border nodes next to h: its new value
                 // would be at least (the smallest of those nodes) + (the cheaper of the two cells it touches on this side)
@@ -902,22 +1124,22 @@ __global__ __launch_bounds__(NTHR, UFM_RELAX_WAVES) void k_relax(DevParams P, in
                     const int crow_r = (er < 0) ? 0 : T;                   // cost row / column of the cells between the tiles
                     const int ccol_c = (ec < 0) ? 0 : T;
                     auto gain_r = [&](int hc) {                           // h = halo row, LDS column hc (node column hc - 1 of the tile)
-                        const float *mine = Gs + (io_r + 1) * GP;          // my border row (new values)
+                        const float *mine = Gs + (wb_r + 1) * GP;          // my border row (new values)
                         const float m3 = fminf(fminf(mine[hc - 1], mine[hc]), mine[hc + 1]);       // (halo columns included: a node of the tile beside
                                                                                            //  this one can be the cheaper end of the edge)
                         const float c2 = fminf(Cs[crow_r * CP + hc - 1], Cs[crow_r * CP + hc]);
-                        return Gs[(io_r + 1 + er) * GP + hc] > m3 + c2;
+                        return Gs[(wb_r + 1 + er) * GP + hc] > m3 + c2;
                     };
                     auto gain_c = [&](int hr) {
-                        const int mc = io_c + 1;
+                        const int mc = wb_c + 1;
                         const float m3 = fminf(fminf(Gs[(hr - 1) * GP + mc], Gs[hr * GP + mc]), Gs[(hr + 1) * GP + mc]);
                         const float c2 = fminf(Cs[(hr - 1) * CP + ccol_c], Cs[hr * CP + ccol_c]);
                         return Gs[hr * GP + mc + ec] > m3 + c2;
                     };
-                    if (er && need_r) need_r = gain_r(cl) || gain_r(io_c + 1) || gain_r(ch);
-                    if (ec && need_c) need_c = gain_c(rl) || gain_c(io_r + 1) || gain_c(rh);
-                    if (er && ec && need_d) need_d = Gs[(io_r + 1 + er) * GP + io_c + 1 + ec] >
-                                                      fminf(gf, fminf(Gs[(io_r + 1 + er) * GP + io_c + 1], Gs[(io_r + 1) * GP + io_c + 1 + ec])) + Cs[crow_r * CP + ccol_c];
+                    if (er && need_r) need_r = gain_r(cl) || gain_r(wb_c + 1) || gain_r(ch);
+                    if (ec && need_c) need_c = gain_c(rl) || gain_c(wb_r + 1) || gain_c(rh);
+                    if (er && ec && need_d) need_d = Gs[(wb_r + 1 + er) * GP + wb_c + 1 + ec] >
+                                                      fminf(gf, fminf(Gs[(wb_r + 1 + er) * GP + wb_c + 1], Gs[(wb_r + 1) * GP + wb_c + 1 + ec])) + Cs[crow_r * CP + ccol_c];
                 }
                 if ((er || ec) && significant && gf > gl0) atomicMin(&s_bmin[4], __float_as_int(gl0));
             }
@@ -926,21 +1148,30 @@ __global__ __launch_bounds__(NTHR, UFM_RELAX_WAVES) void k_relax(DevParams P, in
             if (ec && significant && need_c) atomicMin(&s_bmin[3 + ec + 1], pb);
             if (er && ec && significant && need_d) atomicMin(&s_bmin[(er + 1) * 3 + ec + 1], pb);
         }
+        // resident kernel: the values must have arrived -- and the next tile's mark -- before a neighbour is told
+        if constexpr (OWN) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
+        if (OWN && tid == 0) s_own[3] = own_was;
         if (tid < 9) {
             const int dr = tid / 3 - 1, dc = tid % 3 - 1;
             if (tid == 4) {
-                if (!conv || s_bmin[4] != INFBITS) activate(P, Q, k + 1, gt, min(s_bmin[4], INFBITS - 1));   // sweep cap hit / border rose: come back
+                if (!conv || s_bmin[4] != INFBITS) {           // sweep cap hit / border rose: come back
+                    if (OWN) own_push(P, gt, min(s_bmin[4], INFBITS - 1));
+                    else activate(P, Q, k + 1, gt, min(s_bmin[4], INFBITS - 1));
+                }
                 P.hint[gt] = s_misc[3];
                 // statistics: summed in this thread's registers, flushed once when the workgroup is done
                 // (same-address atomics from 256 CUs are memory-side operations; five per visit add up)
                 st_lmax = max(st_lmax, s_misc[3]);
-                st_visits += 1;
-                st_iters += (unsigned long long)s_misc[3];
-                st_evals += 16ull * (unsigned long long)s_misc[2];
+                s_stat[0] += 1ull;
+                s_stat[1] += (unsigned long long)s_misc[3];
+                s_stat[2] += 16ull * (unsigned long long)s_misc[2];
             } else if (s_bmin[tid] != INFBITS) {
                 const int ntx = tx + dr, nty = ty + dc;
-                if (ntx >= 0 && ntx < P.TX && nty >= 0 && nty < P.TY) activate(P, Q, k + 1, m * P.NTm + ntx * P.TY + nty, s_bmin[tid]);
+                if (ntx >= 0 && ntx < P.TX && nty >= 0 && nty < P.TY) {
+                    if (OWN) own_push(P, m * P.NTm + ntx * P.TY + nty, s_bmin[tid]);
+                    else activate(P, Q, k + 1, m * P.NTm + ntx * P.TY + nty, s_bmin[tid]);
+                }
             }
         }
 #ifdef UFM_TIMING
@@ -958,12 +1189,12 @@ __global__ __launch_bounds__(NTHR, UFM_RELAX_WAVES) void k_relax(DevParams P, in
         }
 #endif
     }
-    if (tid == 4 && st_visits) {
+    if (tid == 4 && s_stat[0]) {
         atomicMax(&P.lmax[k & (LMAX - 1)], st_lmax);
-        atomicAdd(&P.ctr->tile_visits, st_visits);
-        if (MODE == MODE_RAISE) atomicAdd(&P.ctr->raise_visits, st_visits);
-        atomicAdd(&P.ctr->tile_iters, st_iters);
-        atomicAdd(&P.ctr->elem_evals, st_evals);
+        atomicAdd(&P.ctr->tile_visits, s_stat[0]);
+        if (MODE == MODE_RAISE) atomicAdd(&P.ctr->raise_visits, s_stat[0]);
+        atomicAdd(&P.ctr->tile_iters, s_stat[1]);
+        atomicAdd(&P.ctr->elem_evals, s_stat[2]);
     }
 }
 
@@ -1186,6 +1417,39 @@ __device__ void unpark(const DevParams &P, int qz, int k, float rbound, int &s_k
     for (int i = threadIdx.x; i < s_keep; i += blockDim.x) list[i] = tmp[i];
     if (threadIdx.x == 0) P.ctr->npark[qz] = s_keep;
     __syncthreads();
+}
+// The resident lowering kernel stands in for launch k of the lowering queue and everything after it: this kernel hands
+// it the entries of list k % 3 and does the list bookkeeping a launch does for its successors (k_relax, block 0) ...
+__global__ void k_own_import(DevParams P, int k) {
+    const int r = k % 3, rz = (k + 2) % 3;
+    const int n = P.ctr->cnt[Q_LOWER][r];
+    const int *cand = P.cand + (size_t)(Q_LOWER * 3 + r) * P.NT;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const int gt = cand[i];
+        own_push(P, gt, min(prio_read(P, Q_LOWER, k, gt), INFBITS - 1));
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        P.ctr->cnt[Q_LOWER][rz] = 0; P.ctr->rel[Q_LOWER][rz] = 0; P.ctr->lmin[Q_LOWER][rz] = INFBITS;
+        P.ctr->nready[(k + 1) & 1] = 0; P.ctr->nshort[(k + 1) & 1] = 0; P.ctr->rcursor[(k + 1) & 1] = 0;
+        P.ctr->rel[Q_LOWER][r] = n;
+        if (n) P.ctr->last_work[Q_LOWER] = k;
+    }
+}
+// ... and this one gives what it left queued -- tiles beyond the start's key; everything, had it run into its time
+// limit -- back to the launch chain as the list of launch k1 = k + 1, and leaves all words empty.
+__global__ void k_own_export(DevParams P, int k1) {
+    const int total = OWN_NW * P.own_slots;
+    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
+        const int v = P.own_prio[e];
+        if (v == INFBITS) continue;
+        P.own_prio[e] = INFBITS;
+        if (v < INFBITS) {
+            int m, tx, ty;
+            const int o = e / P.own_slots, gt = own_tile(P, o, e - o * P.own_slots, m, tx, ty);
+            if (gt >= 0) activate(P, Q_LOWER, k1, gt, v);
+        }
+    }
+    if (blockIdx.x == 0 && threadIdx.x < OWN_NW) P.own_min[threadIdx.x] = INFBITS;
 }
 __global__ void k_unpark(DevParams P, int qz, int k, float rbound) {
     __shared__ int s_keep;
@@ -1486,6 +1750,12 @@ struct Engine {
     bool spin_wait = true;           // false: hipMemcpyAsync + hipStreamSynchronize instead
     bool fuse_control = true;        // replans: fused control kernels (k_replan_begin / _raise_to_lower / _end)
     bool use_graph = true;           // replans: the whole submission replayed as one captured hipGraph
+    bool use_owned = true;           // plans: the lowering phase as ONE resident launch (k_relax<.,LOWER,false,true>) instead of a launch per band step
+    float owned_limit_ms = 2000.0f;  // ... which hands back to the launch chain after this long, whatever happens
+    float owned_band = -1.0f;        // ... ordering band in tile crossings (< 0: twice delta_scale_long -- nobody waits for a launch to end
+                                     //     here, and a workgroup that finds nothing inside the band idles: wider pays)
+    uint32_t owned_launches = 0;
+    int owned_flags = 0;
     bool use_region = true;          // replans: one workgroup runs both phases in LDS on the block around the patch (ufm_region.h);
                                      // the launch chain only takes over when work is left outside the block
     int region_ahead = 2;            // block placement: tiles kept between the patches' centre and the block's goal-side edge
@@ -1550,6 +1820,7 @@ struct Engine {
     int wait_flag(const unsigned int *flag, unsigned int seq);
     int win_raise[6] = {8, 8, 8, 8, 8, 8}, win_lower[6] = {8, 8, 8, 8, 8, 8}, win_pos = 0;   // launches recent replans needed
     int run_phase(int mode, float rbound, uint32_t *launches, float *kernel_ms, uint32_t *timed);
+    int owned_phase();
     int profile_stride = 4;          // profiling: every n-th launch of a plan is bracketed by events
     int reset_queues();
     int read_bounds(float *bmax);
@@ -1564,7 +1835,7 @@ void Engine::release() {
     std::memset(&graph_sig, 0, sizeof(graph_sig));
     void *ptrs[] = {P.G, P.Gprev, P.ring, P.cost, P.costT, P.goal, P.cand, P.ready, P.hint, P.rank, P.park, P.pflag, P.pprio,
                     P.queued, P.prio, P.start, P.bnd, P.dyn, P.spos, P.touched, P.fresh, P.tlist, P.sflag, P.slist, P.slist2,
-                    P.mark, P.num_updated, P.consume, P.lmax, P.ctr, d_scratch};
+                    P.mark, P.num_updated, P.consume, P.lmax, P.own_prio, P.own_min, P.ctr, d_scratch};
     for (void *q : ptrs) if (q) hipFree(q);
     P = DevParams{};                     // every pointer null again: a failed alloc() can be released, and released twice
     d_scratch = nullptr;
@@ -1589,6 +1860,8 @@ int Engine::alloc(int width, int length) {
     P.gstride = (size_t)P.NTm * TT;
     P.cstride = (size_t)L * W;
     P.mstride = (size_t)P.EX * P.EY;
+    P.own_sx = (P.TX + 15) / 16; P.own_sy = (P.TY + 15) / 16;
+    P.own_slots = nmaps * P.own_sx * P.own_sy;
     allocated = true;                    // from here on release() has something to free, also after a failure half way
     const size_t gbytes = P.gstride * nmaps * sizeof(float);
     int rc = UFM_OK;
@@ -1628,6 +1901,8 @@ int Engine::alloc(int width, int length) {
     dmalloc(P.num_updated, sizeof(unsigned int) * nmaps);
     dmalloc(P.consume, sizeof(int) * nmaps);
     dmalloc(P.lmax, sizeof(int) * LMAX);
+    dmalloc(P.own_prio, sizeof(int) * (size_t)OWN_NW * P.own_slots);
+    dmalloc(P.own_min, sizeof(int) * OWN_NW);
     dmalloc(P.ctr, sizeof(DevCounters));
     dmalloc(d_scratch, sizeof(int) * (4 * nmaps + 4));
     if (rc != UFM_OK) { release(); return rc; }
@@ -1664,6 +1939,8 @@ int Engine::reset_queues() {
     HIPCHK(hipMemsetAsync(P.prio, 0xFF, sizeof(unsigned long long) * 4 * P.NT, stream));   // tag of no launch, larger than any key
     HIPCHK(hipMemsetAsync(P.pflag, 0, sizeof(int) * 2 * P.NT, stream));
     k_fill<<<64, 256, 0, stream>>>(reinterpret_cast<float *>(P.pprio), (size_t)2 * P.NT, INFINITY);
+    k_fill<<<64, 256, 0, stream>>>(reinterpret_cast<float *>(P.own_prio), (size_t)OWN_NW * P.own_slots, INFINITY);   // (+inf = INFBITS: empty)
+    k_fill<<<1, 256, 0, stream>>>(reinterpret_cast<float *>(P.own_min), (size_t)OWN_NW, INFINITY);
     // the queue state at the head of DevCounters: cnt, rel, lmin, npark, nready, rcursor, nshort, last_work, fin_blocks
     static_assert(offsetof(DevCounters, cnt) == 0, "queue state leads the counter block");
     HIPCHK(hipMemsetAsync(P.ctr, 0, offsetof(DevCounters, kbase), stream));
@@ -1833,6 +2110,31 @@ int Engine::launch_relax(int mode, float rbound, hipEvent_t e0, hipEvent_t e1) {
 // b published, batch b+1 is already running (a host round trip -- publish, PCIe, decision, first
 // dispatch -- left the GPU idle for ~15 us, 68 times per 4096^2 plan).  The price: when batch b turns
 // out to have drained the queue, batch b+1 consists of launches that find nothing to do (a few us each).
+// A whole lowering phase in one launch: the resident kernel (k_relax<., LOWER, false, true>) between the two kernels that
+// move the queue into and out of its per-owner words.  What it leaves behind is an ordinary (short or empty) list
+// for launch iter + 1, which run_phase() then finds.
+int Engine::owned_phase() {
+    const int k = iter[Q_LOWER];
+    const float delta = delta_abs >= 0.0f ? delta_abs : (owned_band >= 0.0f ? owned_band : 2.0f * delta_scale_long) * T * mean_cost;
+    P.own_limit = (unsigned long long)((double)owned_limit_ms * 1e5);   // 100 MHz ticks
+    P.own_flags = owned_flags;
+    k_own_import<<<64, 256, 0, stream>>>(P, k);
+    const dim3 g(OWN_NW), b(NTHR);
+    const int ms_ = max_iters;
+#define UFM_LAUNCH(A) k_relax<A, MODE_LOWER, false, true><<<g, b, 0, stream>>>(P, k, delta, INFINITY, ms_)
+    if (algo == UFM_ALGO_FD) UFM_LAUNCH(UFM_ALGO_FD);
+    else if (algo == UFM_ALGO_SG) UFM_LAUNCH(UFM_ALGO_SG);
+    else if (opt_lvl == 0) UFM_LAUNCH(UFM_ALGO_DFM);
+    else UFM_LAUNCH(ALGO_DFM1);
+#undef UFM_LAUNCH
+    k_own_export<<<256, 256, 0, stream>>>(P, k + 1);
+    HIPCHK(hipGetLastError());
+    ++iter[Q_LOWER];
+    last_active = 1;
+    ++owned_launches;
+    return UFM_OK;
+}
+
 int Engine::run_phase(int mode, float rbound, uint32_t *launches, float *kernel_ms, uint32_t *timed) {
     const int q = (mode == MODE_LOWER) ? Q_LOWER : Q_RAISE;
     int batch = batch_fixed > 0 ? batch_fixed : 4;
@@ -2292,6 +2594,11 @@ int Engine::step(ufm_stats *out) {
             const auto tb = std::chrono::steady_clock::now();
             uint32_t ll = 0;
             k_unpark<<<1, 1024, 0, stream>>>(P, Q_LOWER, iter[Q_LOWER], INFINITY);
+            if (use_owned && n_init > 0 && round == 0 && dyn_grid >= OWN_NW) {
+                int rc = owned_phase();
+                if (rc != UFM_OK) return rc;
+                st.launches += 1u;
+            }
             int rc = run_phase(MODE_LOWER, INFINITY, &ll, &st.kernel_ms, &st.timed_launches);
             if (rc != UFM_OK) return rc;
             st.launches += ll;
@@ -2739,6 +3046,10 @@ static int engine_set_param(Engine *e, const char *name, double value) {
     else if (!std::strcmp(name, "fuse_control")) e->fuse_control = value != 0;
     else if (!std::strcmp(name, "graph")) e->use_graph = value != 0;
     else if (!std::strcmp(name, "region")) e->use_region = value != 0;
+    else if (!std::strcmp(name, "owned")) e->use_owned = value != 0;
+    else if (!std::strcmp(name, "owned_limit_ms")) e->owned_limit_ms = (float)value;
+    else if (!std::strcmp(name, "owned_band")) e->owned_band = (float)value;
+    else if (!std::strcmp(name, "owned_flags")) e->owned_flags = (int)value;
     else if (!std::strcmp(name, "region_debug")) e->region_debug = (int)value;
     else if (!std::strcmp(name, "region_band")) e->region_band = (float)value;
     else if (!std::strcmp(name, "region_ahead")) e->region_ahead = (int)value;
