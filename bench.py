@@ -198,7 +198,10 @@ def run_rank(args):
             return {"cells": p.num_nodes_expanded}
         st = p.stats
         d = {"cells": st.expanded, "visits": st.tile_visits, "launches": st.launches, "kernel_ms": st.kernel_ms, "evals": st.elem_evals,
-             "lower_visits": 0, "lower_launches": 0, "lower_kernel_ms": 0.0, "lower_timed": 0}
+             "lower_visits": 0, "lower_launches": 0, "lower_kernel_ms": 0.0, "lower_timed": 0,
+             "res_visits": 0, "res_launches": 0, "res_kernel_ms": 0.0}
+        if st.resident_launches and st.resident_kernel_ms > 0:   # a plan: its lowering phase was one launch of the resident kernel
+            d.update(res_visits=st.resident_tile_visits, res_launches=st.resident_launches, res_kernel_ms=st.resident_kernel_ms)
         timed = st.timed_launches - st.timed_raise_launches
         if timed > 0:   # steps whose lowering launches carry HIP events: the plans (a sample of their launches);
             #             the replans are replayed from a captured graph, whose nodes HIP events cannot time
@@ -351,6 +354,7 @@ def run_rank(args):
     keys = ("cells", "visits", "launches", "kernel_ms", "evals")
     tot = [sum(d.get(k, 0) for d in per_step) for k in keys]
     low = [sum(d.get(k, 0) for d in per_step) for k in ("lower_visits", "lower_launches", "lower_kernel_ms", "lower_timed")]
+    res = [sum(d.get(k, 0) for d in per_step) for k in ("res_visits", "res_launches", "res_kernel_ms")]
 
     # self-check of the patch path (outside the timed region)
     for m, got, expect in self_check():
@@ -404,7 +408,31 @@ def run_rank(args):
         if rehearsal:
             out["rehearsal"] = "CPU stand-in planner %s over %s: control flow only, not a measurement" % (args.planner_factory, args.backend)
         lvis, llaunch, lkms, ltimed = low
-        if not rehearsal and lkms > 0 and llaunch > 0 and ltimed > 0:
+        rvis, rlaunch, rkms = res
+        traffic_ok = args.algo == "FD" and size == 4096 and M == 0 and not args.heuristic
+        if not rehearsal and rlaunch > 0 and rkms > 0:
+            # dominant kernel: the resident lowering kernel, k_relax<algo, LOWER, false, true> -- ONE launch per plan runs the whole
+            # lowering phase.  Algorithmic bytes = its tile visits x (9 B per element + halo) per SURVEY.md 8(d); duration = HIP events
+            # attached to that dispatch on the engine's stream (every launch of it inside the timed region is timed).
+            avg_launch_s = rkms * 1e-3 / rlaunch
+            achieved = (rvis / rlaunch) * BYTES_PER_TILE_VISIT / avg_launch_s / 1e9
+            traffic, traffic_source = None, None
+            tj = os.path.join(ROOT, "profiles", args.traffic_json)
+            if os.path.exists(tj) and traffic_ok:
+                tjd = json.load(open(tj))
+                if "resident" in tjd.get("kernel", ""):
+                    traffic = tjd.get("traffic_bytes_per_launch")
+                    traffic_source = "profiles/%s: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, collected separately (not in this run)" % args.traffic_json
+            out["roofline"] = {
+                "bound": "hbm", "kernel": "k_relax<%s,LOWER,resident> (one launch per plan: the whole lowering phase)" % args.algo, "achieved": achieved,
+                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
+                "avg_launch_us": 1e6 * avg_launch_s, "timed_launches": rlaunch, "launches": rlaunch,
+                "algorithmic_bytes_per_launch": rvis * BYTES_PER_TILE_VISIT / rlaunch,
+                "tile_visits_per_launch": rvis / rlaunch,
+                "kernel_time_share": avg_launch_s * rlaunch / dt,
+                "note": "latency-bound (dependent in-LDS sweeps along the wavefront), not bandwidth-bound: see DESIGN.md",
+            }
+        elif not rehearsal and lkms > 0 and llaunch > 0 and ltimed > 0:
             # dominant kernel: k_relax<algo, LOWER>.  Algorithmic bytes = tile visits x (9 B per element
             # + halo) per SURVEY.md 8(d); duration = HIP events on the engine's stream around its launches.
             # (the events bracket a sample of the launches -- every 16th of a plan --
@@ -413,7 +441,7 @@ def run_rank(args):
             achieved = (lvis / llaunch) * BYTES_PER_TILE_VISIT / avg_launch_s / 1e9
             traffic, traffic_source = None, None
             tj = os.path.join(ROOT, "profiles", args.traffic_json)
-            if os.path.exists(tj) and args.algo == "FD" and size == 4096 and M == 0 and not args.heuristic:
+            if os.path.exists(tj) and traffic_ok and "resident" not in json.load(open(tj)).get("kernel", ""):
                 traffic = json.load(open(tj)).get("traffic_bytes_per_launch")
                 traffic_source = "profiles/%s: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, collected separately (not in this run)" % args.traffic_json
             out["roofline"] = {

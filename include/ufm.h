@@ -63,7 +63,10 @@ typedef struct ufm_stats {
                                     * new heuristic multiplier / threshold must not add one: they travel through memory) */
     uint32_t region_replans;       /* cumulative: replans submitted to the block-resident kernel (one workgroup, both phases in LDS) */
     uint32_t region_replans_done;  /*   ... and completed by it alone (the others were finished by the launch chain) */
-    uint32_t reserved0;
+    uint32_t resident_launches;    /* plans: launches of the resident lowering kernel in this step (0 or 1: it runs a whole lowering phase) */
+    float resident_kernel_ms;      /*   its duration (HIP events attached to the dispatch); 0 unless profiling is on */
+    uint32_t resident_stops;       /*   cumulative: workgroups that left it on its time limit instead of on an empty queue (expected: 0) */
+    uint64_t resident_tile_visits; /*   tile visits it made (part of tile_visits) */
 } ufm_stats;
 
 /* ---- lifetime: `PlannerT<OPT_LVL> planner{}` (e.g. Tests/Planners/FDSTAR/main.cpp:77) ---- */

@@ -48,7 +48,10 @@ class Stats(C.Structure):
         ("graphs_instantiated", C.c_uint32),
         ("region_replans", C.c_uint32),
         ("region_replans_done", C.c_uint32),
-        ("reserved0", C.c_uint32),
+        ("resident_launches", C.c_uint32),
+        ("resident_kernel_ms", C.c_float),
+        ("resident_stops", C.c_uint32),
+        ("resident_tile_visits", C.c_uint64),
     ]
 
     def as_dict(self):

@@ -155,8 +155,9 @@ struct DevCounters {
     unsigned int updated;       // k_check: num_nodes_updated summed over the consuming maps
     int done_fail;              // batch replan round in the block kernel: maps whose workgroup could not finish the replan alone
     unsigned long long raise_visits;   // tile visits of the invalidation kernel (subset of tile_visits)
-    int own_stops;              // resident kernel: workgroups that left on the time limit instead of on an empty queue
+    int own_stops;              // resident kernel: workgroups that left on the time limit instead of on an empty queue (cumulative)
     int own_pad;
+    unsigned long long own_vis0, own_vis1;   // tile_visits before / after the step's resident launch
 };
 
 // Per-step scalars the kernels read from memory, not from their by-value parameter block: the replans are
@@ -1433,6 +1434,7 @@ __global__ void k_own_import(DevParams P, int k) {
         P.ctr->nready[(k + 1) & 1] = 0; P.ctr->nshort[(k + 1) & 1] = 0; P.ctr->rcursor[(k + 1) & 1] = 0;
         P.ctr->rel[Q_LOWER][r] = n;
         if (n) P.ctr->last_work[Q_LOWER] = k;
+        P.ctr->own_vis0 = P.ctr->tile_visits;
     }
 }
 // ... and this one gives what it left queued -- tiles beyond the start's key; everything, had it run into its time
@@ -1450,6 +1452,7 @@ __global__ void k_own_export(DevParams P, int k1) {
         }
     }
     if (blockIdx.x == 0 && threadIdx.x < OWN_NW) P.own_min[threadIdx.x] = INFBITS;
+    if (blockIdx.x == 0 && threadIdx.x == 0) P.ctr->own_vis1 = P.ctr->tile_visits;
 }
 __global__ void k_unpark(DevParams P, int qz, int k, float rbound) {
     __shared__ int s_keep;
@@ -1755,6 +1758,8 @@ struct Engine {
     float owned_band = -1.0f;        // ... ordering band in tile crossings (< 0: twice delta_scale_long -- nobody waits for a launch to end
                                      //     here, and a workgroup that finds nothing inside the band idles: wider pays)
     uint32_t owned_launches = 0;
+    hipEvent_t own_ev[2] = {nullptr, nullptr};
+    bool own_timed = false;
     int owned_flags = 0;
     bool use_region = true;          // replans: one workgroup runs both phases in LDS on the block around the patch (ufm_region.h);
                                      // the launch chain only takes over when work is left outside the block
@@ -2121,7 +2126,13 @@ int Engine::owned_phase() {
     k_own_import<<<64, 256, 0, stream>>>(P, k);
     const dim3 g(OWN_NW), b(NTHR);
     const int ms_ = max_iters;
-#define UFM_LAUNCH(A) k_relax<A, MODE_LOWER, false, true><<<g, b, 0, stream>>>(P, k, delta, INFINITY, ms_)
+    own_timed = false;
+    if (profiling) {
+        for (auto &e : own_ev) if (!e) HIPCHK(hipEventCreate(&e));
+        own_timed = true;
+    }
+#define UFM_LAUNCH(A) do { if (own_timed) hipExtLaunchKernelGGL((k_relax<A, MODE_LOWER, false, true>), g, b, 0, stream, own_ev[0], own_ev[1], 0, P, k, delta, INFINITY, ms_); \
+                           else k_relax<A, MODE_LOWER, false, true><<<g, b, 0, stream>>>(P, k, delta, INFINITY, ms_); } while (0)
     if (algo == UFM_ALGO_FD) UFM_LAUNCH(UFM_ALGO_FD);
     else if (algo == UFM_ALGO_SG) UFM_LAUNCH(UFM_ALGO_SG);
     else if (opt_lvl == 0) UFM_LAUNCH(UFM_ALGO_DFM);
@@ -2598,6 +2609,7 @@ int Engine::step(ufm_stats *out) {
                 int rc = owned_phase();
                 if (rc != UFM_OK) return rc;
                 st.launches += 1u;
+                st.resident_launches += 1u;
             }
             int rc = run_phase(MODE_LOWER, INFINITY, &ll, &st.kernel_ms, &st.timed_launches);
             if (rc != UFM_OK) return rc;
@@ -2627,6 +2639,11 @@ int Engine::step(ufm_stats *out) {
         st.tile_iters = h_ctr->tile_iters;
         st.elem_evals = h_ctr->elem_evals;
         st.raise_tile_visits = h_ctr->raise_visits;
+        if (st.resident_launches) {
+            st.resident_tile_visits = h_ctr->own_vis1 - h_ctr->own_vis0;
+            st.resident_stops = (uint32_t)h_ctr->own_stops;
+            if (own_timed) HIPCHK(hipEventElapsedTime(&st.resident_kernel_ms, own_ev[0], own_ev[1]));
+        }
         if (profiling) {   // diagnostics: sum over launches of the slowest tile's sweep count
             std::vector<int> lm(LMAX);
             HIPCHK(hipMemcpy(lm.data(), P.lmax, sizeof(int) * LMAX, hipMemcpyDeviceToHost));
@@ -2726,6 +2743,7 @@ int engine_destroy(Engine *e) {
     if (e->stream) hipStreamSynchronize(e->stream);
     e->release();
     for (hipEvent_t v : e->ev) hipEventDestroy(v);
+    for (hipEvent_t v : e->own_ev) if (v) hipEventDestroy(v);
     if (e->d_patch) hipFree(e->d_patch);
     if (e->d_pmask) hipFree(e->d_pmask);
     if (e->d_field) hipFree(e->d_field);
@@ -3166,6 +3184,9 @@ int ufm_batch_step(ufm_batch_t *b, ufm_stats *stats) {
             a.crit_sweeps += c.crit_sweeps; a.raise_tile_visits += c.raise_tile_visits; a.raise_kernel_ms += c.raise_kernel_ms;
             a.queued_lower += c.queued_lower; a.queued_raise += c.queued_raise; a.timed_launches += c.timed_launches;
             a.timed_raise_launches += c.timed_raise_launches; a.graphs_instantiated += c.graphs_instantiated;
+            a.region_replans += c.region_replans; a.region_replans_done += c.region_replans_done;
+            a.resident_launches += c.resident_launches; a.resident_kernel_ms += c.resident_kernel_ms;
+            a.resident_stops += c.resident_stops; a.resident_tile_visits += c.resident_tile_visits;
         }
         *stats = a;
     }
