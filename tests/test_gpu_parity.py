@@ -153,7 +153,11 @@ def test_result_independent_of_scheduler_knobs():
     for scale, cap, grid, extra in [(1.0, 128, 512, {}), (0.25, 128, 512, {}), (1e9, 128, 64, {}), (2.0, 3, 7, {}),
                                     (1.5, 32, 64, {"pipeline_batches": 0}),            # host waits for every batch of launches
                                     (1.5, 32, 64, {"delta_scale_long": 3.0, "batch": 2}),   # other band for long queues, short batches
-                                    (1.5, 32, 16, {"dynamic": 0})]:                    # fused triage only
+                                    (1.5, 32, 16, {"dynamic": 0}),                     # fused triage only
+                                    (1.5, 32, 64, {"owned": 0}),                       # the plan through the launch chain, not the resident kernel
+                                    (1.5, 32, 64, {"owned_band": 0.5}),                # resident kernel: narrow band, ...
+                                    (1.5, 5, 64, {"owned_band": 1e9, "owned_flags": 1}),   # ... no band, no tile taken ahead, a low sweep cap,
+                                    (1.5, 32, 64, {"owned_limit_ms": 0.02})]:          # ... and one that runs into its time limit and hands back
         p = ufm_amd.Planner(ufm_amd.ALGO_SG, 0)
         p.set_param("focused", 0); p.set_param("delta_scale", scale); p.set_param("max_iters", cap); p.set_param("grid", grid)
         for name, val in extra.items():
@@ -167,6 +171,32 @@ def test_result_independent_of_scheduler_knobs():
         p.close()
     for f in fields[1:]:
         assert np.array_equal(fields[0], f)
+
+
+@pytest.mark.parametrize("algo,lvl", [("FD", 1), ("SG", 2), ("DFM", 1)])
+def test_resident_plan_kernel(algo, lvl):
+    """The plan's lowering phase as one resident launch (k_relax<., LOWER, false, true>): against the oracle below the start's
+    key; it reports itself in the statistics; cut short by its time limit it hands the queue back to the launch chain, which
+    finishes the plan with the same result."""
+    size = 600
+    cost = ufm_amd.synth.cost_map(11, size, size)
+    start, goal = ufm_amd.synth.start_goal(size, size)
+    o, g = make_pair(ALGOS[algo], lvl, cost, start, goal)
+    assert o.step() == 0 and g.step() == 0
+    st = g.stats
+    assert st.resident_launches == 1 and st.resident_stops == 0
+    assert 0 < st.resident_tile_visits <= st.tile_visits
+    check_parity(o, g, "%s-%d resident" % (algo, lvl))
+    g.close()
+    p = ufm_amd.Planner(ALGOS[algo], lvl)
+    p.set_param("owned_limit_ms", 0.05)
+    p.set_occupancy_threshold(1); p.set_map(cost); p.set_start(*start); p.set_goal(*goal)
+    assert p.step() == 0
+    st = p.stats
+    assert st.resident_launches == 1 and st.resident_stops > 0          # every workgroup left on the limit ...
+    assert st.launches > 9 and st.resident_tile_visits < st.tile_visits  # ... and the launch chain did the rest
+    check_parity(o, p, "%s-%d resident, handed back" % (algo, lvl))
+    p.close()
 
 
 def test_edge_cases():
@@ -360,7 +390,7 @@ def test_replan_submission_variants_agree(algo, lvl):
     rng = np.random.default_rng(3)
     big = rng.integers(1, 200, (70, 70), dtype=np.uint8)
     # default: the block-resident kernel (region); region=0: the launch chain in its submission forms
-    variants = [dict(), dict(region_tiles=3, region_band=0), dict(region=0), dict(region=0, graph=0), dict(region=0, graph=0, fuse_control=0),
+    variants = [dict(), dict(region_tiles=3, region_band=0), dict(region=0), dict(owned=0), dict(region=0, graph=0), dict(region=0, graph=0, fuse_control=0),
                 dict(region=0, graph=0, fuse_control=0, spin_wait=0), dict(region=0, spin_wait=0)]
     results = []
     for full in (1, 0):
