@@ -194,7 +194,7 @@ def test_resident_plan_kernel(algo, lvl):
     assert p.step() == 0
     st = p.stats
     assert st.resident_launches == 1 and st.resident_stops > 0          # every workgroup left on the limit ...
-    assert st.launches > 9 and st.resident_tile_visits < st.tile_visits  # ... and the launch chain did the rest
+    assert st.launches > 1 and st.resident_tile_visits < st.tile_visits  # ... and the launch chain did the rest
     check_parity(o, p, "%s-%d resident, handed back" % (algo, lvl))
     p.close()
 

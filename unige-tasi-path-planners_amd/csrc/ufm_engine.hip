@@ -156,7 +156,7 @@ struct DevCounters {
     int done_fail;              // batch replan round in the block kernel: maps whose workgroup could not finish the replan alone
     unsigned long long raise_visits;   // tile visits of the invalidation kernel (subset of tile_visits)
     int own_stops;              // resident kernel: workgroups that left on the time limit instead of on an empty queue (cumulative)
-    int own_pad;
+    int own_abort;              // resident kernel: a workgroup has left on the time limit -- everybody else follows at its next decision
     unsigned long long own_vis0, own_vis1;   // tile_visits before / after the step's resident launch
 };
 
@@ -607,6 +607,7 @@ __global__ __launch_bounds__(NTHR, UFM_RELAX_WAVES) void k_relax(DevParams P, in
     __shared__ int s_pfh[OWN ? OWN_NW : 1];   // start of the visit in progress (loaded straight into LDS while it sweeps)
     __shared__ int s_se[OWN ? 256 : 1];       // resident kernel: start elements of the first 64 maps (index into G, -1 unused) ...
     __shared__ float s_sh[OWN ? 256 : 1];     // ... and hm * dist(start, element)
+    __shared__ int s_late;      // resident kernel: thread 0 has seen the time limit pass (no more tiles are taken ahead: the next look leaves)
     __shared__ int s_own[4];    // resident kernel, thread 0's book-keeping: 0 slot whose mark is still to be taken back, 1 slot being visited, 2 visits
     __shared__ unsigned long long s_stat[3];   // thread 4's per-workgroup statistics (visits, sweeps, evaluations), flushed once at the end
 
@@ -677,7 +678,7 @@ __global__ __launch_bounds__(NTHR, UFM_RELAX_WAVES) void k_relax(DevParams P, in
     int *const own_q = OWN ? P.own_prio + (size_t)blockIdx.x * P.own_slots : nullptr;
     int own_next = -1, own_slot_now = -1;   // (the same in every thread)
     const unsigned long long own_t0 = OWN ? wall_clock64() : 0ull;
-    if (OWN && tid == 0) { s_own[0] = -1; s_own[1] = -1; s_own[2] = 0; }
+    if (OWN && tid == 0) { s_own[0] = -1; s_own[1] = -1; s_own[2] = 0; s_late = 0; }
     if constexpr (OWN) {   // the start elements of the first 64 maps: address in G and the heuristic term of their keys (start_bound())
         const float hm = P.dyn->hm;
         for (int e = tid; e < 4 * min(P.nmaps, 64); e += NTHR) {
@@ -737,6 +738,7 @@ __global__ __launch_bounds__(NTHR, UFM_RELAX_WAVES) void k_relax(DevParams P, in
                 int hint = INFBITS;
                 if (tid < OWN_NW && tid != (int)blockIdx.x) hint = __hip_atomic_load(&P.own_min[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 const int v0 = tid < P.own_slots ? __hip_atomic_load(&own_q[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : INFBITS;
+                const int aborted = tid == 0 ? __hip_atomic_load(&P.ctr->own_abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
                 own_decide(v0, hint, -1);
                 const unsigned long long b = s_best;
                 const int votes = s_gmin;
@@ -769,8 +771,10 @@ __global__ __launch_bounds__(NTHR, UFM_RELAX_WAVES) void k_relax(DevParams P, in
                 }
                 if (tid == 0) {
                     int flag = 0;
-                    const bool late = !stop && wall_clock64() - own_t0 > P.own_limit;   // hand back to the launch chain (k_own_export): never stay for ever
-                    if (late) atomicAdd(&P.ctr->own_stops, 1);
+                    // hand back to the launch chain (k_own_export): never stay for ever -- and not alone: a workgroup that only became
+                    // resident when the others had left (the device was shared) must not wait out a limit of its own
+                    const bool late = !stop && (aborted || wall_clock64() - own_t0 > P.own_limit);
+                    if (late) { atomicAdd(&P.ctr->own_stops, 1); __hip_atomic_store(&P.ctr->own_abort, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
                     s_own[3] = own_commit(b, take && !stop && !late, true);   // (waits for the exchange: the visit's loads must not overtake
                     if (stop || late) flag = -1;                              //  it -- an activation it removes has to be one whose values
                     else if (take) flag = 1;                                  //  the visit then sees)
@@ -1050,8 +1054,11 @@ __global__ __launch_bounds__(NTHR, UFM_RELAX_WAVES) void k_relax(DevParams P, in
             // queue round trip in between.  (A fresh look costs two round trips in a row -- words, then exchange -- per visit.)
             own_decide(tid < P.own_slots ? s_pf[tid] : INFBITS, (tid < OWN_NW && tid != (int)blockIdx.x) ? s_pfh[tid] : INFBITS, own_slot_now);
             const unsigned long long b = s_best;
-            const bool take = b != ~0ull && !(s_gmin & 2) && !(P.own_flags & 1);
-            if (tid == 0) own_was = own_commit(b, take, false);
+            const bool take = b != ~0ull && !(s_gmin & 2) && !(P.own_flags & 1) && !s_late;
+            if (tid == 0) {
+                own_was = own_commit(b, take, false);
+                if (wall_clock64() - own_t0 > P.own_limit) s_late = 1;   // (a workgroup that is never out of work looks at the clock here)
+            }
             own_next = __builtin_amdgcn_readfirstlane(take ? (int)(unsigned int)b : -1);
         }
         // write back what changed; note which neighbours saw their halo change
@@ -1435,6 +1442,7 @@ __global__ void k_own_import(DevParams P, int k) {
         P.ctr->rel[Q_LOWER][r] = n;
         if (n) P.ctr->last_work[Q_LOWER] = k;
         P.ctr->own_vis0 = P.ctr->tile_visits;
+        P.ctr->own_abort = 0;
     }
 }
 // ... and this one gives what it left queued -- tiles beyond the start's key; everything, had it run into its time
@@ -2605,13 +2613,18 @@ int Engine::step(ufm_stats *out) {
             const auto tb = std::chrono::steady_clock::now();
             uint32_t ll = 0;
             k_unpark<<<1, 1024, 0, stream>>>(P, Q_LOWER, iter[Q_LOWER], INFINITY);
+            int owned_left = -1;
             if (use_owned && n_init > 0 && round == 0 && dyn_grid >= OWN_NW) {
                 int rc = owned_phase();
                 if (rc != UFM_OK) return rc;
                 st.launches += 1u;
                 st.resident_launches += 1u;
+                // what it handed back (nothing, unless it ran into its time limit): no need to send launches after an empty list
+                rc = fetch_counters();
+                if (rc != UFM_OK) return rc;
+                owned_left = h_ctr->cnt[Q_LOWER][iter[Q_LOWER] % 3];
             }
-            int rc = run_phase(MODE_LOWER, INFINITY, &ll, &st.kernel_ms, &st.timed_launches);
+            int rc = owned_left == 0 ? UFM_OK : run_phase(MODE_LOWER, INFINITY, &ll, &st.kernel_ms, &st.timed_launches);
             if (rc != UFM_OK) return rc;
             st.launches += ll;
             bool again = false;
