@@ -156,6 +156,7 @@ def test_result_independent_of_scheduler_knobs():
                                     (1.5, 32, 16, {"dynamic": 0}),                     # fused triage only
                                     (1.5, 32, 64, {"owned": 0}),                       # the plan through the launch chain, not the resident kernel
                                     (1.5, 32, 64, {"owned_band": 0.5}),                # resident kernel: narrow band, ...
+                                    (1.5, 32, 64, {"owned_waves": 8}),                 # ... 8 waves per tile visit (two visits per CU, 512 owners), ...
                                     (1.5, 5, 64, {"owned_band": 1e9, "owned_flags": 1}),   # ... no band, no tile taken ahead, a low sweep cap,
                                     (1.5, 32, 64, {"owned_limit_ms": 0.02})]:          # ... and one that runs into its time limit and hands back
         p = ufm_amd.Planner(ufm_amd.ALGO_SG, 0)
@@ -188,6 +189,13 @@ def test_resident_plan_kernel(algo, lvl):
     assert 0 < st.resident_tile_visits <= st.tile_visits
     check_parity(o, g, "%s-%d resident" % (algo, lvl))
     g.close()
+    p = ufm_amd.Planner(ALGOS[algo], lvl)
+    p.set_param("owned_waves", 8)                                       # the other form: 8 waves per visit, 512 workgroups
+    p.set_occupancy_threshold(1); p.set_map(cost); p.set_start(*start); p.set_goal(*goal)
+    assert p.step() == 0
+    assert p.stats.resident_launches == 1 and p.stats.resident_stops == 0
+    check_parity(o, p, "%s-%d resident, 8 waves" % (algo, lvl))
+    p.close()
     p = ufm_amd.Planner(ALGOS[algo], lvl)
     p.set_param("owned_limit_ms", 0.05)
     p.set_occupancy_threshold(1); p.set_map(cost); p.set_start(*start); p.set_goal(*goal)

@@ -207,7 +207,8 @@ struct DevParams {
     int *own_min;               // [OWN_NW] smallest priority each owner holds (queued or in flight): a hint for the ordering band, not exact
     unsigned long long own_limit;   // wall-clock ticks (100 MHz) after which the resident kernel hands back to the launch chain
     int own_flags;              // diagnostics: 1 = no tile taken ahead (every visit starts with a fresh look at the queue)
-    int own_slots, own_sx, own_sy;  // words per owner = nmaps * own_sx * own_sy; 16 x 16-tile super-blocks per map side
+    int own_slots, own_sx, own_sy;  // words per owner = nmaps * own_sx * own_sy; blocks of 16 x (1 << own_ys) tiles per map side
+    int own_nw, own_ys;             // owners (= workgroups of the resident launch) = 16 << own_ys: 256 (own_ys 4) or 512 (5)
     DevCounters *ctr;
     int EX, EY;                 // elements per map (nodes or cells)
     int L, W;                   // cells per map
@@ -298,19 +299,19 @@ __device__ __forceinline__ float tile_heuristic(const DevParams &P, int m, int t
 // MARK -> empty only after the activations of that visit have been performed: the words of all owners are non-empty
 // as long as anything is queued, in flight, or about to be queued, and two identical all-empty collects of them in a
 // row mean the phase is over (an empty value never repeats, so identical collects are a true snapshot).
-constexpr int OWN_NW = 256;
+constexpr int OWN_NW = 512;    // most owners a launch of the resident kernel has (P.own_nw: 256 or 512)
 constexpr int OWN_MARK = 0x7FFFFFFF;
 __device__ __forceinline__ void own_locate(const DevParams &P, int gt, int &o, int &s) {
     const int m = gt / P.NTm, t = gt - m * P.NTm, tx = t / P.TY, ty = t - tx * P.TY;
-    o = ((tx & 15) << 4) | (ty & 15);
-    s = (m * P.own_sx + (tx >> 4)) * P.own_sy + (ty >> 4);
+    o = ((tx & 15) << P.own_ys) | (ty & ((1 << P.own_ys) - 1));
+    s = (m * P.own_sx + (tx >> 4)) * P.own_sy + (ty >> P.own_ys);
 }
 // tile of slot s of owner o; -1 if that position lies outside the map
 __device__ __forceinline__ int own_tile(const DevParams &P, int o, int s, int &m, int &tx, int &ty) {
     const int per = P.own_sx * P.own_sy;
     m = s / per;
     const int r = s - m * per, bx = r / P.own_sy, by = r - bx * P.own_sy;
-    tx = bx * 16 + (o >> 4); ty = by * 16 + (o & 15);
+    tx = bx * 16 + (o >> P.own_ys); ty = (by << P.own_ys) + (o & ((1 << P.own_ys) - 1));
     return (tx < P.TX && ty < P.TY) ? m * P.NTm + tx * P.TY + ty : -1;
 }
 __device__ __forceinline__ void own_push(const DevParams &P, int gt, int pbits) {
@@ -589,12 +590,22 @@ __global__ void k_cost_windows(DevParams P, int m) {
 // balance, used while the queue is long); !DYN: triage fused as described above (short queues).
 // OWN: the resident form (one launch per lowering phase): no lists at all, every workgroup serves the tiles it owns
 // from their queue words (own_push above) until all of them, everywhere, are empty.
-template <int ALGO, int MODE, bool DYN, bool OWN = false>
-__global__ __launch_bounds__(NTHR, UFM_RELAX_WAVES) void k_relax(DevParams P, int k_arg, float delta, float rbound, int max_sweeps) {
+template <int ALGO, int MODE, bool DYN, int OWNK = 0>   // OWNK: 0 launch chain, 1 resident with 16 waves per visit, 2 resident with 8
+__global__ __launch_bounds__(OWNK == 2 ? NTHR / 2 : NTHR, UFM_RELAX_WAVES) void k_relax(DevParams P, int k_arg, float delta, float rbound, int max_sweeps) {
+    constexpr bool OWN = OWNK != 0;
     static_assert(!OWN || (!DYN && MODE == MODE_LOWER), "the resident kernel lowers");
+    // The resident kernel can give a tile visit 8 waves instead of 16 and run two visits per CU: during the sweeps about five of a
+    // visit's 16 patches are active at a time (the front crosses the tile), so half the waves are idle slots of the SIMDs.
+    // A wave then owns the two patches (pr, pc) with (pr + 2 pc) mod 8 = its index -- no two patches of a row, a column or a
+    // diagonal, the lines a front lies along, share a wave.
+    constexpr int NTH = OWNK == 2 ? NTHR / 2 : NTHR;
+    constexpr int NWV = NTH / 64;
+    constexpr int PPWK = (PT * PT) / NWV;
+    constexpr bool SKEW = (NWV == 8 && PT == 4);
+    static_assert(SKEW || PPWK == PPW, "patch-to-wave maps: 4 x 4 waves of PR x PR patches, or the skewed 8-wave one");
     __shared__ float Gs[(T + 2) * GP];
     __shared__ float Cs[(T + 1) * CP];
-    __shared__ int s_wake[16];  // per wave: bit j = patch j of the wave has new inputs (PPW bits)
+    __shared__ int s_wake[16];  // per wave: bit j = patch j of the wave has new inputs (PPWK bits)
     __shared__ int s_idle;      // waves currently without work
     __shared__ int s_giveup;    // a wave hit the sweep cap: end the visit, re-queue the tile
     __shared__ int s_misc[4];   // 0: first touch, 1: earlier visits in this step, 2: patch sweeps (sum), 3: (max per wave)
@@ -603,7 +614,7 @@ __global__ __launch_bounds__(NTHR, UFM_RELAX_WAVES) void k_relax(DevParams P, in
     __shared__ float s_B[64];   // fused triage: start key of the first 64 maps
     __shared__ unsigned long long s_best;   // resident kernel: {priority, slot} of the best tile this workgroup may take / collect checksum
     __shared__ int s_gmin;      // resident kernel: votes of a decision (own_decide), then what thread 0 made of it (1 take, -1 stop)
-    __shared__ int s_pf[OWN ? NTHR : 1];      // resident kernel: this workgroup's first queue words and the other owners' hints as of the
+    __shared__ int s_pf[OWN ? NTH : 1];      // resident kernel: this workgroup's first queue words and the other owners' hints as of the
     __shared__ int s_pfh[OWN ? OWN_NW : 1];   // start of the visit in progress (loaded straight into LDS while it sweeps)
     __shared__ int s_se[OWN ? 256 : 1];       // resident kernel: start elements of the first 64 maps (index into G, -1 unused) ...
     __shared__ float s_sh[OWN ? 256 : 1];     // ... and hm * dist(start, element)
@@ -646,7 +657,7 @@ __global__ __launch_bounds__(NTHR, UFM_RELAX_WAVES) void k_relax(DevParams P, in
     if (!DYN && !OWN && MODE == MODE_LOWER) {   // smallest priority among the entries that are not parked beyond their map's start key
         // (invalidation is order-free -- delta = +inf --: no band, no scan, two dependent loads less per launch)
         int lmin = INFBITS;
-        for (int i = tid; i < n; i += NTHR) {
+        for (int i = tid; i < n; i += NTH) {
             const int c = (i == tid) ? c_first : cand[i], pb = (i == tid) ? pb_first : prio_read(P, Q, k, c), mm = c / P.NTm;
             const float Bm = mm < 64 ? s_B[mm] : INFINITY;
             if (__int_as_float(pb) < Bm || Bm == INFINITY) lmin = min(lmin, pb);
@@ -681,7 +692,7 @@ __global__ __launch_bounds__(NTHR, UFM_RELAX_WAVES) void k_relax(DevParams P, in
     if (OWN && tid == 0) { s_own[0] = -1; s_own[1] = -1; s_own[2] = 0; s_late = 0; }
     if constexpr (OWN) {   // the start elements of the first 64 maps: address in G and the heuristic term of their keys (start_bound())
         const float hm = P.dyn->hm;
-        for (int e = tid; e < 4 * min(P.nmaps, 64); e += NTHR) {
+        for (int e = tid; e < 4 * min(P.nmaps, 64); e += NTH) {
             const int el = P.start[e], m_ = e >> 2;
             const int x = el / P.EY, y = el - x * P.EY;
             s_se[e] = el >= 0 ? (int)gaddr(P, m_, x, y) : -1;
@@ -697,7 +708,7 @@ __global__ __launch_bounds__(NTHR, UFM_RELAX_WAVES) void k_relax(DevParams P, in
         lds_barrier();
         unsigned long long best = ~0ull;
 #pragma unroll 1
-        for (int sl = tid; sl < P.own_slots; sl += NTHR) {
+        for (int sl = tid; sl < P.own_slots; sl += NTH) {
             const int v = (sl == tid) ? v0 : __hip_atomic_load(&own_q[sl], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (v < INFBITS && sl != skip) best = min(best, ((unsigned long long)(unsigned int)v << 32) | (unsigned int)sl);
         }
@@ -736,7 +747,7 @@ __global__ __launch_bounds__(NTHR, UFM_RELAX_WAVES) void k_relax(DevParams P, in
             while (own_next < 0) {                             // nothing was taken ahead: look, wait, look again
                 __syncthreads();                               // LDS of the previous visit / round is free
                 int hint = INFBITS;
-                if (tid < OWN_NW && tid != (int)blockIdx.x) hint = __hip_atomic_load(&P.own_min[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (tid < P.own_nw && tid != (int)blockIdx.x) hint = __hip_atomic_load(&P.own_min[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 const int v0 = tid < P.own_slots ? __hip_atomic_load(&own_q[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : INFBITS;
                 const int aborted = tid == 0 ? __hip_atomic_load(&P.ctr->own_abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
                 own_decide(v0, hint, -1);
@@ -749,7 +760,7 @@ __global__ __launch_bounds__(NTHR, UFM_RELAX_WAVES) void k_relax(DevParams P, in
                     // nobody seems to hold anything: two collects of all queue words; identical and all empty = the phase is over
                     unsigned long long h0 = 0ull, h1 = 1ull;
                     bool ok = true;
-                    const int total = OWN_NW * P.own_slots;
+                    const int total = P.own_nw * P.own_slots;
                     for (int pass = 0; pass < 2 && ok; ++pass) {
                         __syncthreads();
                         if (tid == 0) s_best = 0ull;
@@ -757,7 +768,7 @@ __global__ __launch_bounds__(NTHR, UFM_RELAX_WAVES) void k_relax(DevParams P, in
                         unsigned long long acc = 0ull;
                         bool mine_ok = true;
 #pragma unroll 1
-                        for (int e = tid; e < total; e += NTHR) {
+                        for (int e = tid; e < total; e += NTH) {
                             const int v = __hip_atomic_load(&P.own_prio[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                             if (v < INFBITS || v == OWN_MARK) mine_ok = false;
                             acc += ((unsigned long long)(unsigned int)v + 1ull) * (0x9E3779B97F4A7C15ull + 2ull * (unsigned long long)e);
@@ -844,7 +855,7 @@ __global__ __launch_bounds__(NTHR, UFM_RELAX_WAVES) void k_relax(DevParams P, in
         // branches), then thread 0's bookkeeping atomics, and only then are the results consumed: one memory
         // round trip in front of the visit.  (Written as guarded blocks -- load, wait, LDS store, each -- the
         // first waves paid three round trips in series, thread 0's wave up to five.)
-        const int ht = tid - (NTHR - (4 * T + 4));               // halo: the last 4T+4 threads of the workgroup
+        const int ht = tid - (NTH - (4 * T + 4));               // halo: the last 4T+4 threads of the workgroup
         constexpr int CN = CROWS * CROWS;
         const float gl0 = ld_f<OWN>(&Gt[io_on ? tid : 0]);
         const float hv = ld_f<OWN>(&ring[ht >= 0 ? ht : 0]);
@@ -859,7 +870,7 @@ __global__ __launch_bounds__(NTHR, UFM_RELAX_WAVES) void k_relax(DevParams P, in
             if (first) P.tlist[atomicAdd(&P.ctr->tcount, 1)] = gt;
             s_misc[0] = first; s_misc[1] = seen; s_misc[2] = 0; s_misc[3] = 0; s_idle = 0; s_giveup = 0;
         }
-        if (tid < 16) s_wake[tid] = (1 << PPW) - 1;
+        if (tid < NWV) s_wake[tid] = (1 << PPWK) - 1;
         if constexpr (OWN) if (focused && w == 0) {
             // End condition: a tile whose priority lies beyond its map's start key (start_bound(): the largest key among the
             // start elements that have been reached) is not relaxed -- it goes to the park list of the launch chain, the
@@ -872,7 +883,7 @@ __global__ __launch_bounds__(NTHR, UFM_RELAX_WAVES) void k_relax(DevParams P, in
                 const float B = m < 64 ? (bq > 0.0f ? bq : INFINITY) : start_bound(P, m);
                 const int kb = s_own[3];                         // the priority the tile was taken with
                 if (!(__int_as_float(kb) + tile_heuristic(P, m, tx, ty) < B || B == INFINITY)) {
-                    for (int j = 0; j < 16; ++j) s_wake[j] = 0;
+                    for (int j = 0; j < NWV; ++j) s_wake[j] = 0;
                     park_tile(P, Q_LOWER, gt, kb);
                 }
             }
@@ -891,7 +902,7 @@ __global__ __launch_bounds__(NTHR, UFM_RELAX_WAVES) void k_relax(DevParams P, in
             Gs[(hr + 1) * GP + hc + 1] = hv;
         }
         // the cost window as float (inf = obstacle / outside: Graph::get_cost, Graph.cpp:262-268)
-        for (int e = tid; e < CN; e += NTHR) {
+        for (int e = tid; e < CN; e += NTH) {
             const int cr = e / CROWS, cc = e - cr * CROWS;
             const int cx = x0 + cr - COFF, cy = y0 + cc - COFF;
             const int c = (e == tid) ? c0 : ct[e];
@@ -914,23 +925,29 @@ __global__ __launch_bounds__(NTHR, UFM_RELAX_WAVES) void k_relax(DevParams P, in
             typedef __attribute__((address_space(3))) void *lds_ptr;
             typedef const __attribute__((address_space(1))) void *glb_ptr;
             __builtin_amdgcn_global_load_lds((glb_ptr)(own_q + min(tid, P.own_slots - 1)), (lds_ptr)(s_pf + (tid & ~63)), 4, 0, 16);              // (16: sc1)
-            if (tid < OWN_NW) __builtin_amdgcn_global_load_lds((glb_ptr)(P.own_min + tid), (lds_ptr)(s_pfh + (tid & ~63)), 4, 0, 16);
+            if (tid < P.own_nw) __builtin_amdgcn_global_load_lds((glb_ptr)(P.own_min + tid), (lds_ptr)(s_pfh + (tid & ~63)), 4, 0, 16);
         }
 
         // per-lane constants of the wave's four patches
-        QuadConsts<ALGO> C[PPW];
-        int off[PPW], wword[PPW], wbit[PPW];
-        bool goal[PPW];
+        QuadConsts<ALGO> C[PPWK];
+        int off[PPWK], wword[PPWK], wbit[PPWK];
+        bool goal[PPWK];
 #pragma unroll
-        for (int j = 0; j < PPW; ++j) {
-            const int lx = (wr * PR + j / PR) * 4 + (nd >> 2), ly = (wc * PR + j % PR) * 4 + (nd & 3);
+        for (int j = 0; j < PPWK; ++j) {
+            int pr_, pc_;                                      // the wave's patch j in the PT x PT patch grid
+            if constexpr (SKEW) { pc_ = j ? (w < 2 ? 3 : (w >> 1)) : (w < 4 ? 0 : (w >> 1) - 1); pr_ = (w - 2 * pc_) & 7; }
+            else { pr_ = wr * PR + j / PR; pc_ = wc * PR + j % PR; }
+            const int lx = pr_ * 4 + (nd >> 2), ly = pc_ * 4 + (nd & 3);
             C[j].load(Cs, lx, ly, q);
             off[j] = (lx + 1) * GP + ly + 1;
             goal[j] = (x0 + lx == goal_x) & (y0 + ly == goal_y);
             wword[j] = 0; wbit[j] = 0;
             if (lane < 9) {
-                const int gr = wr * PR + j / PR + lane / 3 - 1, gc = wc * PR + j % PR + lane % 3 - 1;   // PT x PT patch grid
-                if (gr >= 0 && gr < PT && gc >= 0 && gc < PT) { wword[j] = (gr / PR) * 4 + (gc / PR); wbit[j] = 1 << ((gr % PR) * PR + (gc % PR)); }
+                const int gr = pr_ + lane / 3 - 1, gc = pc_ + lane % 3 - 1;
+                if (gr >= 0 && gr < PT && gc >= 0 && gc < PT) {
+                    if constexpr (SKEW) { const int wv = (gr + 2 * gc) & 7; wword[j] = wv; wbit[j] = (gc == (wv < 4 ? 0 : (wv >> 1) - 1)) ? 1 : 2; }
+                    else { wword[j] = (gr / PR) * 4 + (gc / PR); wbit[j] = 1 << ((gr % PR) * PR + (gc % PR)); }
+                }
             }
         }
 
@@ -945,7 +962,7 @@ __global__ __launch_bounds__(NTHR, UFM_RELAX_WAVES) void k_relax(DevParams P, in
         // transient neighbours.  Two neighbours that feed each other can flip-flop forever if they
         // rise in the same sweep, so an element may only rise in sweeps of its own colour
         // (4-colouring: no two 8-neighbours share one).
-        int cnt[PPW] = {};
+        int cnt[PPWK] = {};
         int tot = 0;
         const bool lax = is_dfm<ALGO> && (s_misc[1] > (ALGO == ALGO_DFM1 ? UFM_DFM1_LAX_VISITS : UFM_DFM_LAX_VISITS));
         bool conv = false;
@@ -961,7 +978,7 @@ __global__ __launch_bounds__(NTHR, UFM_RELAX_WAVES) void k_relax(DevParams P, in
             if (bits && !vote) {
                 UFM_WREC(1, bits);
 #pragma unroll
-                for (int j = 0; j < PPW; ++j) {
+                for (int j = 0; j < PPWK; ++j) {
                     if (!(bits & (1 << j))) continue;    // wave-uniform
                     float *ctr = Gs + off[j];
                     bool again = true;
@@ -1012,7 +1029,7 @@ __global__ __launch_bounds__(NTHR, UFM_RELAX_WAVES) void k_relax(DevParams P, in
                         __hip_atomic_fetch_or(&s_wake[w], 1 << j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 }
                 UFM_WREC(2, tot);
-                if (tot >= PPW * max_sweeps && lane == 0)  // give up this visit; the tile is re-queued
+                if (tot >= PPWK * max_sweeps && lane == 0)  // give up this visit; the tile is re-queued
                     __hip_atomic_store(&s_giveup, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 continue;
             }
@@ -1022,7 +1039,7 @@ __global__ __launch_bounds__(NTHR, UFM_RELAX_WAVES) void k_relax(DevParams P, in
                 UFM_WREC(3, 0);
                 for (;;) {
                     __builtin_amdgcn_s_sleep(UFM_IDLE_SLEEP);
-                    if (__hip_atomic_load(&s_idle, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >= 16 ||
+                    if (__hip_atomic_load(&s_idle, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >= NWV ||
                         __hip_atomic_load(&s_giveup, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != 0) { vote = true; break; }
                     if (__hip_atomic_load(&s_wake[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != 0) {
                         if (lane == 0) atomicSub(&s_idle, 1);
@@ -1052,7 +1069,7 @@ __global__ __launch_bounds__(NTHR, UFM_RELAX_WAVES) void k_relax(DevParams P, in
             // The next tile is chosen and marked now, from the queue words as they were when this visit began to sweep: the
             // exchange is on its way while this visit is written back, and the next visit's loads follow the write-back with no
             // queue round trip in between.  (A fresh look costs two round trips in a row -- words, then exchange -- per visit.)
-            own_decide(tid < P.own_slots ? s_pf[tid] : INFBITS, (tid < OWN_NW && tid != (int)blockIdx.x) ? s_pfh[tid] : INFBITS, own_slot_now);
+            own_decide(tid < P.own_slots ? s_pf[tid] : INFBITS, (tid < P.own_nw && tid != (int)blockIdx.x) ? s_pfh[tid] : INFBITS, own_slot_now);
             const unsigned long long b = s_best;
             const bool take = b != ~0ull && !(s_gmin & 2) && !(P.own_flags & 1) && !s_late;
             if (tid == 0) {
@@ -1448,7 +1465,7 @@ __global__ void k_own_import(DevParams P, int k) {
 // ... and this one gives what it left queued -- tiles beyond the start's key; everything, had it run into its time
 // limit -- back to the launch chain as the list of launch k1 = k + 1, and leaves all words empty.
 __global__ void k_own_export(DevParams P, int k1) {
-    const int total = OWN_NW * P.own_slots;
+    const int total = P.own_nw * P.own_slots;
     for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
         const int v = P.own_prio[e];
         if (v == INFBITS) continue;
@@ -1459,7 +1476,7 @@ __global__ void k_own_export(DevParams P, int k1) {
             if (gt >= 0) activate(P, Q_LOWER, k1, gt, v);
         }
     }
-    if (blockIdx.x == 0 && threadIdx.x < OWN_NW) P.own_min[threadIdx.x] = INFBITS;
+    if (blockIdx.x == 0) for (int i = threadIdx.x; i < OWN_NW; i += blockDim.x) P.own_min[i] = INFBITS;
     if (blockIdx.x == 0 && threadIdx.x == 0) P.ctr->own_vis1 = P.ctr->tile_visits;
 }
 __global__ void k_unpark(DevParams P, int qz, int k, float rbound) {
@@ -1769,6 +1786,7 @@ struct Engine {
     hipEvent_t own_ev[2] = {nullptr, nullptr};
     bool own_timed = false;
     int owned_flags = 0;
+    int owned_waves = 0;             // waves per tile visit of the resident kernel: 16 (256 workgroups), 8 (512), 0 = by the size of the job
     bool use_region = true;          // replans: one workgroup runs both phases in LDS on the block around the patch (ufm_region.h);
                                      // the launch chain only takes over when work is left outside the block
     int region_ahead = 2;            // block placement: tiles kept between the patches' centre and the block's goal-side edge
@@ -1834,6 +1852,15 @@ struct Engine {
     int win_raise[6] = {8, 8, 8, 8, 8, 8}, win_lower[6] = {8, 8, 8, 8, 8, 8}, win_pos = 0;   // launches recent replans needed
     int run_phase(int mode, float rbound, uint32_t *launches, float *kernel_ms, uint32_t *timed);
     int owned_phase();
+    void own_layout(int ys) {            // the owner pattern: 16 x (1 << ys) tiles per block, one word per block and map for each owner
+        P.own_ys = ys; P.own_nw = 16 << ys;
+        P.own_sx = (P.TX + 15) / 16; P.own_sy = (P.TY + (1 << ys) - 1) >> ys;
+        P.own_slots = nmaps * P.own_sx * P.own_sy;
+    }
+    size_t own_words() const {           // words of the queue array: enough for either pattern
+        const size_t sx = (size_t)(P.TX + 15) / 16;
+        return (size_t)nmaps * sx * std::max<size_t>(256 * (size_t)((P.TY + 15) / 16), 512 * (size_t)((P.TY + 31) / 32));
+    }
     int profile_stride = 4;          // profiling: every n-th launch of a plan is bracketed by events
     int reset_queues();
     int read_bounds(float *bmax);
@@ -1873,8 +1900,7 @@ int Engine::alloc(int width, int length) {
     P.gstride = (size_t)P.NTm * TT;
     P.cstride = (size_t)L * W;
     P.mstride = (size_t)P.EX * P.EY;
-    P.own_sx = (P.TX + 15) / 16; P.own_sy = (P.TY + 15) / 16;
-    P.own_slots = nmaps * P.own_sx * P.own_sy;
+    own_layout(4);
     allocated = true;                    // from here on release() has something to free, also after a failure half way
     const size_t gbytes = P.gstride * nmaps * sizeof(float);
     int rc = UFM_OK;
@@ -1914,7 +1940,7 @@ int Engine::alloc(int width, int length) {
     dmalloc(P.num_updated, sizeof(unsigned int) * nmaps);
     dmalloc(P.consume, sizeof(int) * nmaps);
     dmalloc(P.lmax, sizeof(int) * LMAX);
-    dmalloc(P.own_prio, sizeof(int) * (size_t)OWN_NW * P.own_slots);
+    dmalloc(P.own_prio, sizeof(int) * own_words());
     dmalloc(P.own_min, sizeof(int) * OWN_NW);
     dmalloc(P.ctr, sizeof(DevCounters));
     dmalloc(d_scratch, sizeof(int) * (4 * nmaps + 4));
@@ -1952,8 +1978,8 @@ int Engine::reset_queues() {
     HIPCHK(hipMemsetAsync(P.prio, 0xFF, sizeof(unsigned long long) * 4 * P.NT, stream));   // tag of no launch, larger than any key
     HIPCHK(hipMemsetAsync(P.pflag, 0, sizeof(int) * 2 * P.NT, stream));
     k_fill<<<64, 256, 0, stream>>>(reinterpret_cast<float *>(P.pprio), (size_t)2 * P.NT, INFINITY);
-    k_fill<<<64, 256, 0, stream>>>(reinterpret_cast<float *>(P.own_prio), (size_t)OWN_NW * P.own_slots, INFINITY);   // (+inf = INFBITS: empty)
-    k_fill<<<1, 256, 0, stream>>>(reinterpret_cast<float *>(P.own_min), (size_t)OWN_NW, INFINITY);
+    k_fill<<<64, 256, 0, stream>>>(reinterpret_cast<float *>(P.own_prio), own_words(), INFINITY);   // (+inf = INFBITS: empty)
+    k_fill<<<2, 256, 0, stream>>>(reinterpret_cast<float *>(P.own_min), (size_t)OWN_NW, INFINITY);
     // the queue state at the head of DevCounters: cnt, rel, lmin, npark, nready, rcursor, nshort, last_work, fin_blocks
     static_assert(offsetof(DevCounters, cnt) == 0, "queue state leads the counter block");
     HIPCHK(hipMemsetAsync(P.ctr, 0, offsetof(DevCounters, kbase), stream));
@@ -2131,16 +2157,23 @@ int Engine::owned_phase() {
     const float delta = delta_abs >= 0.0f ? delta_abs : (owned_band >= 0.0f ? owned_band : 2.0f * delta_scale_long) * T * mean_cost;
     P.own_limit = (unsigned long long)((double)owned_limit_ms * 1e5);   // 100 MHz ticks
     P.own_flags = owned_flags;
+    const bool half = owned_waves == 8 || (owned_waves == 0 && (nmaps > 1 || P.NTm > 150000));
+    own_layout(half ? 5 : 4);
     k_own_import<<<64, 256, 0, stream>>>(P, k);
-    const dim3 g(OWN_NW), b(NTHR);
+    // 16 waves per tile visit, one visit per CU -- or 8 and two: a visit is then ~17 % longer and a CU makes 1.7 x as many.  That pays
+    // where there are always more tiles to visit than workgroups (several maps, or a front as long as that of an 8192^2 map); a single
+    // 4096^2 plan is bound by the chain of dependent visits along the front's way, not by their number
+    const dim3 g(P.own_nw), b(half ? NTHR / 2 : NTHR);
     const int ms_ = max_iters;
     own_timed = false;
     if (profiling) {
         for (auto &e : own_ev) if (!e) HIPCHK(hipEventCreate(&e));
         own_timed = true;
     }
-#define UFM_LAUNCH(A) do { if (own_timed) hipExtLaunchKernelGGL((k_relax<A, MODE_LOWER, false, true>), g, b, 0, stream, own_ev[0], own_ev[1], 0, P, k, delta, INFINITY, ms_); \
-                           else k_relax<A, MODE_LOWER, false, true><<<g, b, 0, stream>>>(P, k, delta, INFINITY, ms_); } while (0)
+#define UFM_LAUNCH(A) do { if (own_timed) { if (half) hipExtLaunchKernelGGL((k_relax<A, MODE_LOWER, false, 2>), g, b, 0, stream, own_ev[0], own_ev[1], 0, P, k, delta, INFINITY, ms_); \
+                                                else hipExtLaunchKernelGGL((k_relax<A, MODE_LOWER, false, 1>), g, b, 0, stream, own_ev[0], own_ev[1], 0, P, k, delta, INFINITY, ms_); } \
+                           else if (half) k_relax<A, MODE_LOWER, false, 2><<<g, b, 0, stream>>>(P, k, delta, INFINITY, ms_); \
+                           else k_relax<A, MODE_LOWER, false, 1><<<g, b, 0, stream>>>(P, k, delta, INFINITY, ms_); } while (0)
     if (algo == UFM_ALGO_FD) UFM_LAUNCH(UFM_ALGO_FD);
     else if (algo == UFM_ALGO_SG) UFM_LAUNCH(UFM_ALGO_SG);
     else if (opt_lvl == 0) UFM_LAUNCH(UFM_ALGO_DFM);
@@ -2614,7 +2647,7 @@ int Engine::step(ufm_stats *out) {
             uint32_t ll = 0;
             k_unpark<<<1, 1024, 0, stream>>>(P, Q_LOWER, iter[Q_LOWER], INFINITY);
             int owned_left = -1;
-            if (use_owned && n_init > 0 && round == 0 && dyn_grid >= OWN_NW) {
+            if (use_owned && n_init > 0 && round == 0 && dyn_grid >= 256) {
                 int rc = owned_phase();
                 if (rc != UFM_OK) return rc;
                 st.launches += 1u;
@@ -3081,6 +3114,7 @@ static int engine_set_param(Engine *e, const char *name, double value) {
     else if (!std::strcmp(name, "owned_limit_ms")) e->owned_limit_ms = (float)value;
     else if (!std::strcmp(name, "owned_band")) e->owned_band = (float)value;
     else if (!std::strcmp(name, "owned_flags")) e->owned_flags = (int)value;
+    else if (!std::strcmp(name, "owned_waves")) e->owned_waves = (int)value;
     else if (!std::strcmp(name, "region_debug")) e->region_debug = (int)value;
     else if (!std::strcmp(name, "region_band")) e->region_band = (float)value;
     else if (!std::strcmp(name, "region_ahead")) e->region_ahead = (int)value;
