@@ -411,7 +411,7 @@ def run_rank(args):
         rvis, rlaunch, rkms = res
         traffic_ok = args.algo == "FD" and size == 4096 and M == 0 and not args.heuristic
         if not rehearsal and rlaunch > 0 and rkms > 0:
-            # dominant kernel: the resident lowering kernel, k_relax<algo, LOWER, false, true> -- ONE launch per plan runs the whole
+            # dominant kernel: the resident lowering kernel, k_relax<algo, LOWER, false, 1 | 2> -- ONE launch per plan runs the whole
             # lowering phase.  Algorithmic bytes = its tile visits x (9 B per element + halo) per SURVEY.md 8(d); duration = HIP events
             # attached to that dispatch on the engine's stream (every launch of it inside the timed region is timed).
             avg_launch_s = rkms * 1e-3 / rlaunch

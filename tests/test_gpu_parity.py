@@ -176,7 +176,7 @@ def test_result_independent_of_scheduler_knobs():
 
 @pytest.mark.parametrize("algo,lvl", [("FD", 1), ("SG", 2), ("DFM", 1)])
 def test_resident_plan_kernel(algo, lvl):
-    """The plan's lowering phase as one resident launch (k_relax<., LOWER, false, true>): against the oracle below the start's
+    """The plan's lowering phase as one resident launch (k_relax<., LOWER, false, 1 | 2>): against the oracle below the start's
     key; it reports itself in the statistics; cut short by its time limit it hands the queue back to the launch chain, which
     finishes the plan with the same result."""
     size = 600

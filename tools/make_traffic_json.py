@@ -37,15 +37,15 @@ def kernel(name):
             "traffic_bytes_per_launch": 1024.0 * (corr_r * f + corr_w * w),
             "rocprof_avg_launch_us": avg_us, "rocprof_calls": calls}
 
-main = kernel("k_relax<0, 0, false, true>")
+main = kernel("k_relax<0, 0, false, 1>")
 out = {
-    "kernel": "k_relax<FD,LOWER,resident> = k_relax<0, 0, false, true> in %s_kernel_stats.csv: the resident lowering kernel, one launch per plan (the whole lowering phase); the launch bench.py brackets with HIP events" % tag,
+    "kernel": "k_relax<FD,LOWER,resident> = k_relax<0, 0, false, 1> in %s_kernel_stats.csv (16 waves per tile visit, 256 workgroups): the resident lowering kernel, one launch per plan (the whole lowering phase); the launch bench.py brackets with HIP events" % tag,
     "fetch_correction": corr_r, "write_correction": corr_w,
     "calibration": "tools/traffic_calib.hip: 1 GiB dword stream -> FETCH_SIZE %.0f KB, WRITE_SIZE %.0f KB" % (cal_r, cal_w),
     "command": "python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline (rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes; tools/collect_profiles.sh)",
     "other_instantiations": {
-        "k_relax<0, 0, false, false> (lowering, launch chain, short queues: after the resident kernel and for the replans the block kernel leaves)": kernel("k_relax<0, 0, false, false>"),
-        "k_relax<0, 1, false, false> (invalidation, launch chain)": kernel("k_relax<0, 1, false, false>"),
+        "k_relax<0, 0, false, 0> (lowering, launch chain, short queues: after the resident kernel and for the replans the block kernel leaves)": kernel("k_relax<0, 0, false, 0>"),
+        "k_relax<0, 1, false, 0> (invalidation, launch chain)": kernel("k_relax<0, 1, false, 0>"),
         "k_replan_region<0> (block-resident replan: both phases of a replan in one workgroup)": kernel("k_replan_region<0>"),
     },
 }

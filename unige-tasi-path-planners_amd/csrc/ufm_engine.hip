@@ -202,7 +202,7 @@ struct DevParams {
     unsigned int *num_updated;  // [nmaps]
     int *consume;               // [nmaps]
     int *lmax;                  // [LMAX] diagnostics: per launch, the largest per-wave sweep count of any tile
-    int *own_prio;              // [OWN_NW][own_slots] resident lowering kernel (k_relax<.,LOWER,false,true>): the queue, one word per tile, grouped
+    int *own_prio;              // [OWN_NW][own_slots] resident lowering kernel (k_relax<.,LOWER,false,1|2>): the queue, one word per tile, grouped
                                 // by the workgroup that owns the tile -- float bits of its priority, >= INFBITS = not queued (see own_push)
     int *own_min;               // [OWN_NW] smallest priority each owner holds (queued or in flight): a hint for the ordering band, not exact
     unsigned long long own_limit;   // wall-clock ticks (100 MHz) after which the resident kernel hands back to the launch chain
@@ -1778,7 +1778,7 @@ struct Engine {
     bool spin_wait = true;           // false: hipMemcpyAsync + hipStreamSynchronize instead
     bool fuse_control = true;        // replans: fused control kernels (k_replan_begin / _raise_to_lower / _end)
     bool use_graph = true;           // replans: the whole submission replayed as one captured hipGraph
-    bool use_owned = true;           // plans: the lowering phase as ONE resident launch (k_relax<.,LOWER,false,true>) instead of a launch per band step
+    bool use_owned = true;           // plans: the lowering phase as ONE resident launch (k_relax<.,LOWER,false,1|2>) instead of a launch per band step
     float owned_limit_ms = 2000.0f;  // ... which hands back to the launch chain after this long, whatever happens
     float owned_band = -1.0f;        // ... ordering band in tile crossings (< 0: twice delta_scale_long -- nobody waits for a launch to end
                                      //     here, and a workgroup that finds nothing inside the band idles: wider pays)
@@ -2149,7 +2149,7 @@ int Engine::launch_relax(int mode, float rbound, hipEvent_t e0, hipEvent_t e1) {
 // b published, batch b+1 is already running (a host round trip -- publish, PCIe, decision, first
 // dispatch -- left the GPU idle for ~15 us, 68 times per 4096^2 plan).  The price: when batch b turns
 // out to have drained the queue, batch b+1 consists of launches that find nothing to do (a few us each).
-// A whole lowering phase in one launch: the resident kernel (k_relax<., LOWER, false, true>) between the two kernels that
+// A whole lowering phase in one launch: the resident kernel (k_relax<., LOWER, false, 1 | 2>) between the two kernels that
 // move the queue into and out of its per-owner words.  What it leaves behind is an ordinary (short or empty) list
 // for launch iter + 1, which run_phase() then finds.
 int Engine::owned_phase() {
