@@ -775,8 +775,14 @@ def test_batch_device_inputs_and_sharded_handle():
             k, s, top, left, patch = scripts[i][r]
             dp = DeviceBytes(patch); keep.append(dp)
             a.patch_map(i, patch, top, left); b.patch_map_device(i, dp.data_ptr(), top, left, 31, 31)
+            if r == 1 and i == 0:      # a second patch of the same map that overlaps the first (device patches are held back until
+                p2 = np.ascontiguousarray(patch[::-1, ::-1][:20, :17])      # the step: their order must survive that)
+                dp2 = DeviceBytes(p2); keep.append(dp2)
+                a.patch_map(i, p2, top + 5, left + 7); b.patch_map_device(i, dp2.data_ptr(), top + 5, left + 7, 17, 20)
             for p in (a, b):
                 p.set_start(i, *s)
+        if r == 2:                     # a read of the raster between patch and step sees the patch
+            assert np.array_equal(a.read_map(1, size, size), b.read_map(1, size, size))
         assert a.step() == 0 and b.step() == 0
         assert b.stats.updated == a.stats.updated
         for i in range(n):

@@ -1378,6 +1378,21 @@ __global__ __launch_bounds__(1024) void k_patch_small(DevParams P, int m, const 
     const int ne = NODES ? (w + 1) * (h + 1) : w * h;
     for (int base = 0; base < ne; base += blockDim.x) patch_seed<NODES>(P, m, pmask, x, y, w, h, base + threadIdx.x);
 }
+// Small patches of several maps, handed over as device pointers and held back until the step that consumes them: one
+// launch, one workgroup per patch (a batch's eight patch kernels in a row were 60 us of every replan round).
+constexpr int PATCH_MULTI = 16;
+struct PatchMulti { int n; int rect[PATCH_MULTI][5]; const uint8_t *ptr[PATCH_MULTI]; };
+template <bool NODES>
+__global__ __launch_bounds__(1024) void k_patch_multi(DevParams P, PatchMulti a, uint8_t *pmask) {
+    const int *q = a.rect[blockIdx.x];
+    const int m = q[0], x = q[1], y = q[2], w = q[3], h = q[4];
+    const uint8_t *patch = a.ptr[blockIdx.x];
+    uint8_t *pm = pmask + (size_t)blockIdx.x * 4096;
+    for (int e = threadIdx.x; e < w * h; e += blockDim.x) patch_apply(P, m, patch, pm, x, y, w, h, e);
+    __syncthreads();
+    const int ne = NODES ? (w + 1) * (h + 1) : w * h;
+    for (int base = 0; base < ne; base += blockDim.x) patch_seed<NODES>(P, m, pm, x, y, w, h, base + threadIdx.x);
+}
 __device__ __forceinline__ void clear_mark(const DevParams &P, int m, int x, int y, int w, int h, int e) {
     const int r = e / (w + 1), c = e - r * (w + 1);
     if (r > h) return;
@@ -1865,13 +1880,20 @@ struct Engine {
     int reset_queues();
     int read_bounds(float *bmax);
     int step(ufm_stats *out);
-    int patch(int m, const uint8_t *dev_patch, int x, int y, int w, int h);
+    int patch(int m, const uint8_t *dev_patch, int x, int y, int w, int h, bool may_defer = false);
+    // Small patches handed over as device pointers are held back until something needs them applied (the next step, a read
+    // of the raster, a path extraction): the caller keeps such a buffer valid until the next step() has returned anyway.
+    struct DeferredPatch { int m, x, y, w, h; const uint8_t *ptr; };
+    std::vector<DeferredPatch> deferred;
+    bool defer_patches = true;
+    int flush_deferred();
 };
 
 void Engine::release() {
     if (!allocated) return;
     if (stream) hipStreamSynchronize(stream);
     drop_graphs();                       // captured kernel arguments hold these pointers
+    deferred.clear();
     std::memset(&graph_sig, 0, sizeof(graph_sig));
     void *ptrs[] = {P.G, P.Gprev, P.ring, P.cost, P.costT, P.goal, P.cand, P.ready, P.hint, P.rank, P.park, P.pflag, P.pprio,
                     P.queued, P.prio, P.start, P.bnd, P.dyn, P.spos, P.touched, P.fresh, P.tlist, P.sflag, P.slist, P.slist2,
@@ -2275,16 +2297,47 @@ int Engine::run_phase(int mode, float rbound, uint32_t *launches, float *kernel_
     }
 }
 
-int Engine::patch(int m, const uint8_t *dev_patch, int x, int y, int w, int h) {
+int Engine::flush_deferred() {
+    if (deferred.empty()) return UFM_OK;
+    PatchMulti a{};
+    a.n = (int)deferred.size();
+    for (int i = 0; i < a.n; ++i) {
+        const DeferredPatch &d = deferred[i];
+        int *q = a.rect[i]; q[0] = d.m; q[1] = d.x; q[2] = d.y; q[3] = d.w; q[4] = d.h;
+        a.ptr[i] = d.ptr;
+    }
+    deferred.clear();
+    if (algo == UFM_ALGO_DFM) k_patch_multi<false><<<a.n, 1024, 0, stream>>>(P, a, d_pmask);
+    else k_patch_multi<true><<<a.n, 1024, 0, stream>>>(P, a, d_pmask);
+    HIPCHK(hipGetLastError());
+    return UFM_OK;
+}
+
+int Engine::patch(int m, const uint8_t *dev_patch, int x, int y, int w, int h, bool may_defer) {
     if (m < 0 || m >= nmaps || !allocated || !maps[m].have_map) return UFM_ERR_INVALID;
     if (x < 0 || y < 0 || w <= 0 || h <= 0 || x + h > L || y + w > W) return UFM_ERR_INVALID;   // Graph.cpp:38-41
     const int n = w * h;
-    if ((size_t)n > d_pmask_cap) {
-        if (d_pmask) { HIPCHK(hipStreamSynchronize(stream)); hipFree(d_pmask); d_pmask = nullptr; d_pmask_cap = 0; }
-        const size_t cap = n < 4096 ? 4096 : (size_t)n;
-        HIPCHK(hipMalloc(&d_pmask, cap));
-        d_pmask_cap = cap;
+    {   // room for the masks of PATCH_MULTI small patches, or of one large one
+        const size_t need = std::max((size_t)PATCH_MULTI * 4096, (size_t)n);
+        if (need > d_pmask_cap) {
+            { int rc = flush_deferred(); if (rc != UFM_OK) return rc; }
+            if (d_pmask) { HIPCHK(hipStreamSynchronize(stream)); hipFree(d_pmask); d_pmask = nullptr; d_pmask_cap = 0; }
+            HIPCHK(hipMalloc(&d_pmask, need));
+            d_pmask_cap = need;
+        }
     }
+    // (a batch only: the patch kernel of a single map runs while the host prepares the step -- applying it inside the
+    //  replan's block kernel instead was tried and saved nothing, it only made that kernel longer)
+    if (may_defer && defer_patches && nmaps > 1 && n <= 4096) {
+        // (one per map at a time: two patches of one map may overlap, and then their order counts)
+        bool clash = (int)deferred.size() >= PATCH_MULTI;
+        for (const DeferredPatch &d : deferred) clash = clash || d.m == m;
+        if (clash) { int rc = flush_deferred(); if (rc != UFM_OK) return rc; }
+        deferred.push_back({m, x, y, w, h, dev_patch});
+        pending.push_back({m, x, y, w, h});
+        return UFM_OK;
+    }
+    { int rc = flush_deferred(); if (rc != UFM_OK) return rc; }   // keep the order of the patches
     if (n <= 4096) {
         if (algo == UFM_ALGO_DFM) k_patch_small<false><<<1, 1024, 0, stream>>>(P, m, dev_patch, d_pmask, x, y, w, h);
         else k_patch_small<true><<<1, 1024, 0, stream>>>(P, m, dev_patch, d_pmask, x, y, w, h);
@@ -2305,8 +2358,9 @@ int Engine::step(ufm_stats *out) {
     for (int m = 0; m < nmaps; ++m) if (!maps[m].goal_set) return UFM_LOOP_FAILURE_NO_GOAL;
     ufm_stats st{};
     const auto t0 = std::chrono::steady_clock::now();
-
     const bool single = (nmaps == 1);
+    { int rc = flush_deferred(); if (rc != UFM_OK) return rc; }   // the patches held back: applied now, in one launch
+
     if (!single) {
         HIPCHK(hipMemsetAsync(&P.ctr->tcount, 0, sizeof(int), stream));
         HIPCHK(hipMemsetAsync(&P.ctr->expanded, 0, 4 * sizeof(unsigned long long), stream));
@@ -2813,6 +2867,7 @@ int engine_destroy(Engine *e) {
 int engine_set_map(Engine *e, int m, const uint8_t *src, bool on_device, int width, int length) {
     if (!e || !src || m < 0 || m >= e->nmaps || width <= 0 || length <= 0) return UFM_ERR_INVALID;
     HIPCHK(hipSetDevice(e->device));
+    if (e->allocated) { int rc = e->flush_deferred(); if (rc != UFM_OK) return rc; }   // (patches held back belong before the new raster)
     if (!e->allocated || width != e->W || length != e->L) {
         bool others = false;
         for (int k = 0; k < e->nmaps; ++k) if (k != m && e->maps[k].have_map) others = true;
@@ -2842,7 +2897,7 @@ int engine_set_map(Engine *e, int m, const uint8_t *src, bool on_device, int wid
 int engine_patch(Engine *e, int m, const uint8_t *src, bool on_device, int x, int y, int w, int h) {
     if (!e || !src) return UFM_ERR_INVALID;
     HIPCHK(hipSetDevice(e->device));
-    if (on_device) return e->patch(m, src, x, y, w, h);
+    if (on_device) return e->patch(m, src, x, y, w, h, true);
     if (w <= 0 || h <= 0) return UFM_ERR_INVALID;
     const size_t n = (size_t)w * h;
     if (n > e->d_patch_cap) {
@@ -2904,6 +2959,7 @@ int engine_extract_path(Engine *e, int max_steps, int lookahead, int allow_indir
     if ((cap_pts > 0 && !path_xy) || (cap_costs > 0 && !step_costs)) return UFM_ERR_INVALID;
     for (const MapState &ms : e->maps) if (!ms.have_map || !ms.start_set || !ms.goal_set) return UFM_ERR_INVALID;
     HIPCHK(hipSetDevice(e->device));
+    { int rc = e->flush_deferred(); if (rc != UFM_OK) return rc; }   // (the walk reads the raster)
     const auto t0 = std::chrono::steady_clock::now();
     const int n = e->nmaps;
     // the device keeps what the caller has room for, at most what max_steps moves can produce
@@ -3063,6 +3119,7 @@ static int engine_check_layout(Engine *e, uint64_t *bad_ring, uint64_t *bad_cost
     if (!e || !e->allocated) return UFM_ERR_INVALID;
     for (const MapState &ms : e->maps) if (!ms.have_map) return UFM_ERR_INVALID;
     HIPCHK(hipSetDevice(e->device));
+    { int rc = e->flush_deferred(); if (rc != UFM_OK) return rc; }
     unsigned long long *d_acc = reinterpret_cast<unsigned long long *>(e->d_scratch);
     HIPCHK(hipMemsetAsync(d_acc, 0, 2 * sizeof(unsigned long long), e->stream));
     k_check_layout<<<1024, 256, 0, e->stream>>>(e->P, d_acc);
@@ -3090,6 +3147,7 @@ int ufm_batch_check_layout(ufm_batch_t *b, uint64_t *bad_ring, uint64_t *bad_cos
 static int engine_read_map(Engine *e, int m, uint8_t *host_map) {
     if (!e || !host_map || !e->allocated || m < 0 || m >= e->nmaps) return UFM_ERR_INVALID;
     HIPCHK(hipSetDevice(e->device));
+    { int rc = e->flush_deferred(); if (rc != UFM_OK) return rc; }
     HIPCHK(hipMemcpyAsync(host_map, e->P.cost + (size_t)m * e->P.cstride, e->P.cstride, hipMemcpyDeviceToHost, e->stream));
     HIPCHK(hipStreamSynchronize(e->stream));
     return UFM_OK;
@@ -3115,6 +3173,7 @@ static int engine_set_param(Engine *e, const char *name, double value) {
     else if (!std::strcmp(name, "owned_band")) e->owned_band = (float)value;
     else if (!std::strcmp(name, "owned_flags")) e->owned_flags = (int)value;
     else if (!std::strcmp(name, "owned_waves")) e->owned_waves = (int)value;
+    else if (!std::strcmp(name, "defer_patches")) { if (e->allocated) { int rc = e->flush_deferred(); if (rc != UFM_OK) return rc; } e->defer_patches = value != 0; }
     else if (!std::strcmp(name, "region_debug")) e->region_debug = (int)value;
     else if (!std::strcmp(name, "region_band")) e->region_band = (float)value;
     else if (!std::strcmp(name, "region_ahead")) e->region_ahead = (int)value;
