@@ -1794,7 +1794,8 @@ struct Engine {
     bool fuse_control = true;        // replans: fused control kernels (k_replan_begin / _raise_to_lower / _end)
     bool use_graph = true;           // replans: the whole submission replayed as one captured hipGraph
     bool use_owned = true;           // plans: the lowering phase as ONE resident launch (k_relax<.,LOWER,false,1|2>) instead of a launch per band step
-    float owned_limit_ms = 2000.0f;  // ... which hands back to the launch chain after this long, whatever happens
+    float owned_limit_ms = -1.0f;    // ... which hands back to the launch chain after this long, whatever happens (< 0: by the size of the job,
+                                     //     ~15 x what a plan of that many tiles takes: a device shared with another long-running kernel)
     float owned_band = -1.0f;        // ... ordering band in tile crossings (< 0: twice delta_scale_long -- nobody waits for a launch to end
                                      //     here, and a workgroup that finds nothing inside the band idles: wider pays)
     uint32_t owned_launches = 0;
@@ -2177,7 +2178,8 @@ int Engine::launch_relax(int mode, float rbound, hipEvent_t e0, hipEvent_t e1) {
 int Engine::owned_phase() {
     const int k = iter[Q_LOWER];
     const float delta = delta_abs >= 0.0f ? delta_abs : (owned_band >= 0.0f ? owned_band : 2.0f * delta_scale_long) * T * mean_cost;
-    P.own_limit = (unsigned long long)((double)owned_limit_ms * 1e5);   // 100 MHz ticks
+    const double limit_ms = owned_limit_ms >= 0.0f ? (double)owned_limit_ms : 200.0 + (double)P.NT / 250.0;   // (4096^2: 0.46 s; its plan takes 17 ms)
+    P.own_limit = (unsigned long long)(limit_ms * 1e5);   // 100 MHz ticks
     P.own_flags = owned_flags;
     const bool half = owned_waves == 8 || (owned_waves == 0 && (nmaps > 1 || P.NTm > 150000));
     own_layout(half ? 5 : 4);
