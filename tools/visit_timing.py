@@ -29,9 +29,6 @@ def report(tag, p):
     v = max(d[3], 1)
     print("%s: launches %d kernel_ms %.2f visits %d | per visit: stage %.2f us  sweeps %.2f us  writeback %.2f us  total %.2f us" % (
         tag, p.stats.launches, p.stats.kernel_ms, d[3], d[0] / v / 100, d[1] / v / 100, d[2] / v / 100, (d[0] + d[1] + d[2]) / v / 100))
-    print("   wb timeline of thread 0 (us after the sweeps): decided %.2f committed %.2f stores+filter issued %.2f waited %.2f barrier passed %.2f" % (d[4] / v / 100, d[5] / v / 100, d[6] / v / 100, d[7] / v / 100, d[60] / v / 100))
-    if d[62]:
-        print("   resident kernel, per decision: queued tiles of the owner inside the band %.2f (decisions %d; tiles left waiting behind the one taken: %d)" % (d[61] / d[62], d[62], d[63]))  # in-band backlog
     print("   visit-time histogram (2 us bins): " + " ".join("%d" % d[8 + i] for i in range(32)))
     print("   per-wave sweep-count histogram:   " + " ".join("%d" % d[40 + i] for i in range(24)))
 
