@@ -95,6 +95,12 @@ constexpr int NTHR = 1024;     // 16 waves; four lanes per node, each wave owns 
 #else
 #define UFM_SWEEP_FENCE() asm volatile("" ::: "memory")
 #endif
+#ifndef UFM_EARLY_HANDOFF
+#define UFM_EARLY_HANDOFF 1    // resident kernel, FD / SG: a border patch that has gone quiet writes its lowered border values out and
+#endif                         // queues the neighbours at once, while the rest of the tile is still being swept (k_relax)
+#ifndef UFM_EARLY_POLLS
+#define UFM_EARLY_POLLS 6      // ... its queue words follow after this many looks of the idle wave at its wake bits (the stores have landed by then)
+#endif
 #ifndef UFM_IDLE_SLEEP
 #define UFM_IDLE_SLEEP 4
 #endif
@@ -314,11 +320,30 @@ __device__ __forceinline__ int own_tile(const DevParams &P, int o, int s, int &m
     tx = bx * 16 + (o >> P.own_ys); ty = (by << P.own_ys) + (o & ((1 << P.own_ys) - 1));
     return (tx < P.TX && ty < P.TY) ? m * P.NTm + tx * P.TY + ty : -1;
 }
-__device__ __forceinline__ void own_push(const DevParams &P, int gt, int pbits) {
+#ifdef UFM_TIMING
+// per tile (resident kernel): [0] first visit start, [1] end of the last visit that changed a value, [2] earliest activation not yet
+// taken, [3] visits, [4] sum of activation -> visit start waits; 100 MHz ticks since the launch's first visit (g_tile_t0)
+constexpr int TILE_DIAG_MAX = 1 << 19;
+__device__ unsigned int g_tile[5][TILE_DIAG_MAX];
+__device__ unsigned long long g_tile_t0;
+// ... and the visits themselves, for the critical path: {tile, start, end, earliest activation taken: time, tile that sent it}
+constexpr int VIS_DIAG_MAX = 1 << 20;
+__device__ unsigned long long g_push64[TILE_DIAG_MAX];     // per tile: {time, sender} of the earliest activation not yet taken
+__device__ unsigned int g_vis[VIS_DIAG_MAX][5];
+__device__ unsigned int g_nvis;
+#endif
+__device__ __forceinline__ void own_push(const DevParams &P, int gt, int pbits, int from = -1) {
     int o, s;
     own_locate(P, gt, o, s);
     __hip_atomic_fetch_min(&P.own_prio[(size_t)o * P.own_slots + s], pbits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __hip_atomic_fetch_min(&P.own_min[o], pbits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#ifdef UFM_TIMING
+    if (gt < TILE_DIAG_MAX) {
+        const unsigned int now = (unsigned int)(wall_clock64() - g_tile_t0);
+        atomicMin(&g_tile[2][gt], now);
+        atomicMin(&g_push64[gt], ((unsigned long long)now << 32) | (unsigned int)from);
+    }
+#endif
 }
 // Values other workgroups write while the resident kernel runs are read and written past the per-XCD L2
 // (agent-scope accesses); the launch-per-band-step kernels rely on the kernel boundaries instead.
@@ -621,6 +646,16 @@ __global__ __launch_bounds__(OWNK == 2 ? NTHR / 2 : NTHR, UFM_RELAX_WAVES) void 
     __shared__ int s_late;      // resident kernel: thread 0 has seen the time limit pass (no more tiles are taken ahead: the next look leaves)
     __shared__ int s_own[4];    // resident kernel, thread 0's book-keeping: 0 slot whose mark is still to be taken back, 1 slot being visited, 2 visits
     __shared__ unsigned long long s_stat[3];   // thread 4's per-workgroup statistics (visits, sweeps, evaluations), flushed once at the end
+    // resident kernel, node planners: border values are handed to the neighbours DURING the visit (early hand-off, below):
+    // Os = what HBM holds for every element of the tile (as staged, then as last written), s_emin = per wave and direction the
+    // smallest border value an early write has changed
+    constexpr bool EARLY = OWN && UFM_EARLY_HANDOFF && !is_dfm<ALGO>;
+    __shared__ float Os[EARLY ? TT : 1];
+    __shared__ int s_emin[EARLY ? 16 * 9 : 1];
+#ifdef UFM_TIMING
+    __shared__ unsigned int s_misc_vi;
+#endif
+    __shared__ int s_qw[2];       // in-visit refresh: [0] this tile's queue word as an idle wave last saw it (loaded straight into LDS), [1] refreshes of this visit
 
     const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
     const int q = lane & 3, nd = lane >> 2;                    // quad lane, node within the 4x4 patch
@@ -818,6 +853,19 @@ __global__ __launch_bounds__(OWNK == 2 ? NTHR / 2 : NTHR, UFM_RELAX_WAVES) void 
             break;
         }
         UFM_TICK(tk0);
+#ifdef UFM_TIMING
+        if (OWN && tid == 0 && gt_own >= 0 && gt_own < TILE_DIAG_MAX) {
+            const unsigned int now = (unsigned int)(tk0 - g_tile_t0);
+            atomicMin(&g_tile[0][gt_own], now);
+            const unsigned int pushed = atomicExch(&g_tile[2][gt_own], 0xFFFFFFFFu);
+            if (pushed != 0xFFFFFFFFu && now > pushed) atomicAdd(&g_tile[4][gt_own], now - pushed);
+            atomicAdd(&g_tile[3][gt_own], 1u);
+            const unsigned long long p64 = atomicExch(&g_push64[gt_own], ~0ull);
+            const unsigned int vi = atomicAdd(&g_nvis, 1u);
+            s_misc_vi = vi;
+            if (vi < VIS_DIAG_MAX) { g_vis[vi][0] = gt_own; g_vis[vi][1] = now; g_vis[vi][2] = 0u; g_vis[vi][3] = (unsigned int)(p64 >> 32); g_vis[vi][4] = (unsigned int)p64; }
+        }
+#endif
         const int gt = OWN ? gt_own : (DYN ? (i < n_long ? (i == (int)blockIdx.x ? spec_first : P.ready[i]) : P.ready[P.NT - 1 - (i - n_long)]) : cand[i]);
         const int pbits = (DYN || OWN) ? 0 : prio_read(P, Q, k, gt);
         const int m = gt / P.NTm, t = gt - m * P.NTm;
@@ -908,6 +956,7 @@ __global__ __launch_bounds__(OWNK == 2 ? NTHR / 2 : NTHR, UFM_RELAX_WAVES) void 
             const int c = (e == tid) ? c0 : ct[e];
             Cs[cr * CP + cc] = (cx < 0 || cy < 0 || cx >= P.L || cy >= P.W || c >= thr) ? INFINITY : (float)c;
         }
+        if constexpr (EARLY) { if (io_on) Os[tid] = gl0; if (tid < NWV * 9) s_emin[tid] = INFBITS; if (tid == 0) { s_qw[0] = OWN_MARK; s_qw[1] = 0; } }
         __syncthreads();
         UFM_TICK(tk1);
 #ifdef UFM_TIMING
@@ -915,6 +964,115 @@ __global__ __launch_bounds__(OWNK == 2 ? NTHR / 2 : NTHR, UFM_RELAX_WAVES) void 
         const int dbg_rank = P.rank[gt];
         const int dbg_ninf0 = __syncthreads_count(io_on && gl0 == INFINITY);
 #endif
+        // One changed element (r, c) of the tile goes out: its value (was `gref` in HBM) into the tile's own record and into the rings
+        // of the neighbours it borders; bm[9] (LDS, float bits, one entry per direction, 4 = this tile itself) notes the smallest changed
+        // value each neighbour has to hear of.  Used by the write-back at the end of a visit and by the early hand-off during it.
+        auto wb_store = [&](int wb_r, int wb_c, float gf) {
+            st_f<OWN>(&Gt[wb_r * T + wb_c], gf);
+#ifdef UFM_TIMING
+            s_qw[1] |= 0x10000;      // (diagnostics: the visit changed a value)
+#endif
+            {   // a border value also lives in the rings of the neighbours it borders
+                const int er_ = (wb_r == 0) ? -1 : ((wb_r == T - 1) ? 1 : 0);
+                const int ec_ = (wb_c == 0) ? -1 : ((wb_c == T - 1) ? 1 : 0);
+                const bool rok = er_ && tx + er_ >= 0 && tx + er_ < P.TX, cok = ec_ && ty + ec_ >= 0 && ty + ec_ < P.TY;
+                if (rok) st_f<OWN>(&P.ring[(size_t)(gt + er_ * P.TY) * RING + (er_ < 0 ? RING_BOT : RING_TOP) + wb_c], gf);
+                if (cok) st_f<OWN>(&P.ring[(size_t)(gt + ec_) * RING + (ec_ < 0 ? RING_RIGHT : RING_LEFT) + wb_r], gf);
+                if (rok && cok)   // my corner (er_, ec_) is the opposite corner of the diagonal neighbour's halo
+                    st_f<OWN>(&P.ring[(size_t)(gt + er_ * P.TY + ec_) * RING + RING_CORNER + (er_ < 0 ? 2 : 0) + (ec_ < 0 ? 1 : 0)], gf);
+            }
+        };
+        // ... and which neighbours have to hear of it.  Bit 0: the one across this element's row border, 1: across its column border,
+        // 2: the diagonal one, 3: this tile itself (a border value that rose)
+        auto wb_need = [&](int wb_r, int wb_c, float gf, float gl0) -> int {
+            // DFM only: the float fixed point of the upwind quadratic is not unique (DESIGN.md section 6);
+            // neighbouring tiles can push each other's border values up one ulp at a time for tens of
+            // thousands of launches.  An INCREASE of at most 4 ulp (a rounding-level correction, never
+            // new information) is stored but does not wake the neighbour; after 24 visits of a tile in
+            // one step the same holds for decreases.  Well inside DFM's 1e-6 tolerance.
+            bool significant = true;
+            if (is_dfm<ALGO> && MODE == MODE_LOWER && gf < INFINITY && gl0 < INFINITY) {
+                const int du = __float_as_int(gf) - __float_as_int(gl0);
+                // (level 1: only in a tile that keeps coming back -- the rises of its operator are corrections of
+                //  values latched from transient neighbours and have to travel)
+                if (ALGO == UFM_ALGO_DFM ? (du > 0 ? du <= 4 : (s_misc[1] > UFM_DFM_QUIET_VISITS && du >= -4))
+                                         : (s_misc[1] > UFM_DFM1_QUIET_VISITS && du >= -4 && du <= 4)) significant = false;
+            }
+            const int er = (wb_r == 0) ? -1 : ((wb_r == T - 1) ? 1 : 0);
+            const int ec = (wb_c == 0) ? -1 : ((wb_c == T - 1) ? 1 : 0);
+            // Causality: every value the update operators produce is larger than each input it
+            // depends on (the interpolated cost-to-goal of the far edge plus a positive traversal
+            // cost), so an element h of a neighbour tile can neither be lowered by nor have been
+            // supported by a border value that is, before and after this visit, not below h: the
+            // wake-up -- half of all tile visits used to find nothing to do -- is skipped.  h is read
+            // from the halo as staged.  A neighbour that is being visited in this same launch only
+            // lowers its border meanwhile, which keeps the test conservative -- except for the
+            // ulp-level rises of replace semantics: a tile whose own border ROSE during a visit
+            // therefore comes back once more (s_bmin[4]) and re-reads its neighbours' borders.
+            bool need_r = true, need_c = true, need_d = true;
+            if (UFM_CAUSAL_FILTER && MODE == MODE_LOWER) {
+                const float lo = fminf(gf, gl0);
+                const int cl = max(wb_c - 1, 0) + 1, ch = min(wb_c + 1, T - 1) + 1;     // halo columns / rows that belong
+                const int rl = max(wb_r - 1, 0) + 1, rh = min(wb_r + 1, T - 1) + 1;     // to the edge neighbour itself
+                if (er) {
+                    const float *h = Gs + (wb_r + 1 + er) * GP;
+                    need_r = lo < fmaxf(fmaxf(h[cl], h[wb_c + 1]), h[ch]);
+                }
+                if (ec) {
+                    const int hc = wb_c + 1 + ec;
+                    need_c = lo < fmaxf(fmaxf(Gs[rl * GP + hc], Gs[(wb_r + 1) * GP + hc]), Gs[rh * GP + hc]);
+                }
+                if (er && ec) need_d = lo < Gs[(wb_r + 1 + er) * GP + wb_c + 1 + ec];
+                // Node planners, lowered value: sharper.  Whatever a neighbour's border node h can gain from this side
+                // comes over the row of cells between the two tiles, from the border nodes next to h: its new value
+                // would be at least (the smallest of those nodes) + (the cheaper of the two cells it touches on this side)
+                // x (one edge length).  (The nodes next to h in the halo belong to a third tile; if one of them is being
+                // lowered in this very launch, this tile sees its old value -- but then it is that tile's visit that
+                // holds the edge's cheaper end and makes the same test with the right number.)  A neighbour whose border already lies below that -- a front running beside
+                // this tile, a step ahead of it -- has nothing to gain and is not woken (41 % of the plan's tile visits
+                // found nothing to do with the test above alone).  Rises keep the test above: an ulp-level correction
+                // must reach whoever was computed from the old value.
+                if (UFM_STEP_FILTER && !is_dfm<ALGO> && gf < gl0) {
+                    const int crow_r = (er < 0) ? 0 : T;                   // cost row / column of the cells between the tiles
+                    const int ccol_c = (ec < 0) ? 0 : T;
+                    auto gain_r = [&](int hc) {                           // h = halo row, LDS column hc (node column hc - 1 of the tile)
+                        const float *mine = Gs + (wb_r + 1) * GP;          // my border row (new values)
+                        const float m3 = fminf(fminf(mine[hc - 1], mine[hc]), mine[hc + 1]);       // (halo columns included: a node of the tile beside
+                                                                                           //  this one can be the cheaper end of the edge)
+                        const float c2 = fminf(Cs[crow_r * CP + hc - 1], Cs[crow_r * CP + hc]);
+                        return Gs[(wb_r + 1 + er) * GP + hc] > m3 + c2;
+                    };
+                    auto gain_c = [&](int hr) {
+                        const int mc = wb_c + 1;
+                        const float m3 = fminf(fminf(Gs[(hr - 1) * GP + mc], Gs[hr * GP + mc]), Gs[(hr + 1) * GP + mc]);
+                        const float c2 = fminf(Cs[(hr - 1) * CP + ccol_c], Cs[hr * CP + ccol_c]);
+                        return Gs[hr * GP + mc + ec] > m3 + c2;
+                    };
+                    if (er && need_r) need_r = gain_r(cl) || gain_r(wb_c + 1) || gain_r(ch);
+                    if (ec && need_c) need_c = gain_c(rl) || gain_c(wb_r + 1) || gain_c(rh);
+                    if (er && ec && need_d) need_d = Gs[(wb_r + 1 + er) * GP + wb_c + 1 + ec] >
+                                                      fminf(gf, fminf(Gs[(wb_r + 1 + er) * GP + wb_c + 1], Gs[(wb_r + 1) * GP + wb_c + 1 + ec])) + Cs[crow_r * CP + ccol_c];
+                }
+            }
+            int need = 0;
+            if (UFM_CAUSAL_FILTER && MODE == MODE_LOWER && (er || ec) && significant && gf > gl0) need |= 8;
+            if (er && significant && need_r) need |= 1;
+            if (ec && significant && need_c) need |= 2;
+            if (er && ec && significant && need_d) need |= 4;
+            return need;
+        };
+        // bm[9] (LDS, float bits; one entry per direction, 4 = this tile itself): the smallest changed value each neighbour has to hear
+        // of = its priority: the new value (lowering) / the value that was invalidated (raising: the reference's key of an
+        // under-consistent element, min(g, rhs) = g)
+        auto wb_note = [&](int wb_r, int wb_c, int need, float gf, float gl0, int *bm) {
+            const int pb = __float_as_int((MODE == MODE_LOWER) ? gf : gl0);
+            const int er = (wb_r == 0) ? -1 : ((wb_r == T - 1) ? 1 : 0);
+            const int ec = (wb_c == 0) ? -1 : ((wb_c == T - 1) ? 1 : 0);
+            if (need & 8) atomicMin(&bm[4], __float_as_int(gl0));
+            if (need & 1) atomicMin(&bm[(er + 1) * 3 + 1], pb);
+            if (need & 2) atomicMin(&bm[3 + ec + 1], pb);
+            if (need & 4) atomicMin(&bm[(er + 1) * 3 + ec + 1], pb);
+        };
         if (s_misc[0]) {   // first touch of the tile in this step: snapshot for num_nodes_expanded -- unless there is nothing
             // to remember (a plan's tiles hold only +inf: 1 KB of writes per tile and as many reads at the end saved)
             const int any = __syncthreads_or(io_on && gl0 != INFINITY);
@@ -964,6 +1122,82 @@ __global__ __launch_bounds__(OWNK == 2 ? NTHR / 2 : NTHR, UFM_RELAX_WAVES) void 
         // (4-colouring: no two 8-neighbours share one).
         int cnt[PPWK] = {};
         int tot = 0;
+        int ew_done = 0;      // early hand-off: patches of this wave that have handed their border out once in this visit
+        int ew_pend = 0;      // ... border values of this wave are on their way to HBM, the neighbours have not been queued yet
+        // the wave's early stores have to have arrived before a neighbour is told (as in the write-back: stores, wait, queue words)
+        auto ew_flush = [&]() {
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            int t_ = tid;
+            asm volatile("" : "+v"(t_));
+            const int l_ = t_ & 63;
+            if (l_ < 9 && l_ != 4) {
+                int *bm = s_emin + (t_ >> 6) * 9;
+                const int v = __hip_atomic_exchange(&bm[l_], INFBITS, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                if (v != INFBITS) {
+                    const int ntx = tx + l_ / 3 - 1, nty = ty + l_ % 3 - 1;
+                    if (ntx >= 0 && ntx < P.TX && nty >= 0 && nty < P.TY) own_push(P, m * P.NTm + ntx * P.TY + nty, v, gt);
+                }
+            }
+            ew_pend = 0;
+        };
+        // In-visit refresh, the other half of the early hand-off: a neighbour that hands its border out while this tile is being
+        // visited lowers this tile's queue word (MARK -> a priority).  Idle waves look at the word now and then (a load straight into
+        // LDS, nobody waits for it); the one that finds it changed takes the activation back (exchange -> MARK, waited for: its values
+        // are then visible), reloads the ring record into the LDS halo and wakes the border patches on the sides that changed --
+        // the visit carries on with the new inputs instead of ending, being written back, queued, taken and staged again.
+        auto halo_poll = [&]() {
+            typedef __attribute__((address_space(3))) void *lds_ptr;
+            typedef const __attribute__((address_space(1))) void *glb_ptr;
+            if (lane == 0) __builtin_amdgcn_global_load_lds((glb_ptr)(own_q + own_slot_now), (lds_ptr)s_qw, 4, 0, 16);
+        };
+        auto halo_refresh = [&]() -> bool {      // true: this wave did a refresh (it has left the idle count meanwhile)
+            int seen = __hip_atomic_load(&s_qw[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (seen == OWN_MARK) return false;
+            int mine = 0;
+            if (lane == 0) mine = atomicCAS(&s_qw[0], seen, OWN_MARK) == seen;
+            if (!__builtin_amdgcn_readfirstlane(mine)) return false;
+            if (lane == 0) { atomicSub(&s_idle, 1); s_qw[1] += 1; }
+#ifdef UFM_TIMING
+            if (lane == 0 && gt < TILE_DIAG_MAX) atomicExch(&g_tile[2][gt], 0xFFFFFFFFu);
+#endif
+            int was = OWN_MARK;
+            if (lane == 0) was = __hip_atomic_exchange(&own_q[own_slot_now], OWN_MARK, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            was = __builtin_amdgcn_readfirstlane(was);
+            if (was < INFBITS) {                 // (an activation: its values were stored before it was queued)
+                int t_ = tid;
+                asm volatile("" : "+v"(t_));
+                const int l_ = t_ & 63;
+                const float h0 = ld_f<true>(&ring[l_]);
+                const float h1 = ld_f<true>(&ring[64 + (l_ & 3)]);
+                int sides = 0;                   // 1 top, 2 bottom, 4 left, 8 right
+                auto put = [&](int ht, float v) {
+                    int hr, hc, sd;
+                    if (ht < T) { hr = -1; hc = ht; sd = 1; }
+                    else if (ht < 2 * T) { hr = T; hc = ht - T; sd = 2; }
+                    else if (ht < 3 * T) { hr = ht - 2 * T; hc = -1; sd = 4; }
+                    else if (ht < 4 * T) { hr = ht - 3 * T; hc = T; sd = 8; }
+                    else { hr = (ht & 2) ? T : -1; hc = (ht & 1) ? T : -1; sd = ((ht & 2) ? 2 : 1) | ((ht & 1) ? 8 : 4); }
+                    float *d = &Gs[(hr + 1) * GP + hc + 1];
+                    if (*d != v) { *d = v; sides |= sd; }
+                };
+                put(l_, h0);
+                if (l_ < 4) put(64 + l_, h1);
+                for (int o_ = 32; o_; o_ >>= 1) sides |= __shfl_xor(sides, o_);
+                UFM_SWEEP_FENCE();               // values before wake bits
+                if (sides && l_ < PT * PT) {
+                    const int pr_ = l_ / PT, pc_ = l_ % PT;
+                    const bool hit = ((sides & 1) && pr_ == 0) || ((sides & 2) && pr_ == PT - 1) || ((sides & 4) && pc_ == 0) || ((sides & 8) && pc_ == PT - 1);
+                    if (hit) {
+                        int wv, bit;
+                        if constexpr (SKEW) { wv = (pr_ + 2 * pc_) & 7; bit = (pc_ == (wv < 4 ? 0 : (wv >> 1) - 1)) ? 1 : 2; }
+                        else { wv = (pr_ / PR) * 4 + (pc_ / PR); bit = 1 << ((pr_ % PR) * PR + (pc_ % PR)); }
+                        __hip_atomic_fetch_or(&s_wake[wv], bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    }
+                }
+            }
+            return true;
+        };
         const bool lax = is_dfm<ALGO> && (s_misc[1] > (ALGO == ALGO_DFM1 ? UFM_DFM1_LAX_VISITS : UFM_DFM_LAX_VISITS));
         bool conv = false;
 #ifdef UFM_TIMING
@@ -1027,6 +1261,36 @@ __global__ __launch_bounds__(OWNK == 2 ? NTHR / 2 : NTHR, UFM_RELAX_WAVES) void 
                     }
                     if (again && lane == 0)              // burst cap: leave the rest to the next take
                         __hip_atomic_fetch_or(&s_wake[w], 1 << j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    if constexpr (EARLY) if (!(P.own_flags & 2)) {
+                        // Early hand-off.  A plan is a chain of dependent tile visits: the next tile on a front's way can
+                        // only start when this visit has been written back, although its inputs -- this tile's far border -- are usually
+                        // there long before the visit ends (the rest of it is the tile settling behind the front).  So a border patch
+                        // whose burst is over and has LOWERED border values writes them out at once (tile record + the neighbours' rings,
+                        // the same code and the same wake-up filters as the write-back) and queues the neighbours, in this order:
+                        // stores, wait for them, queue words -- per wave what the write-back does per workgroup.  Os remembers what
+                        // HBM holds, so the write-back at the end of the visit only handles what has changed since.  Rises (ulp-level
+                        // corrections) wait for the write-back.
+                        int t_ = tid;
+                        asm volatile("" : "+v"(t_));     // (nothing of this is to be computed ahead of the sweeps and carried through them)
+                        const int w_ = t_ >> 6, l_ = t_ & 63;
+                        int pr_, pc_;
+                        if constexpr (SKEW) { pc_ = j ? (w_ < 2 ? 3 : (w_ >> 1)) : (w_ < 4 ? 0 : (w_ >> 1) - 1); pr_ = (w_ - 2 * pc_) & 7; }
+                        else { pr_ = (w_ >> 2) * PR + j / PR; pc_ = (w_ & 3) * PR + j % PR; }
+                        if ((pr_ == 0 || pr_ == PT - 1 || pc_ == 0 || pc_ == PT - 1) && !((P.own_flags & 4) && (ew_done & (1 << j)))) {      // (wave-uniform)
+                            const int lx = pr_ * 4 + (l_ >> 4), ly = pc_ * 4 + ((l_ >> 2) & 3);
+                            const bool onb = (lx == 0) | (lx == T - 1) | (ly == 0) | (ly == T - 1);
+                            const float o = Os[lx * T + ly];
+                            const bool chg = onb & (g < o) & ((l_ & 3) == 0);
+                            const int need = chg ? (wb_need(lx, ly, g, o) & 7) : 0;
+                            if (__builtin_amdgcn_ballot_w64(need != 0) != 0ull) {        // (a neighbour has something to gain: otherwise nothing is written)
+                                int *bm = s_emin + w_ * 9;
+                                ew_done |= 1 << j;
+                                if (chg) { Os[lx * T + ly] = g; wb_store(lx, ly, g); wb_note(lx, ly, need, g, o, bm); }
+                                if (P.own_flags & 8) ew_flush();     // (variant: wait for the stores here, in the sweep loop)
+                                else ew_pend = 1;                    // the queue words follow when the wave has nothing to sweep (idle loop)
+                            }
+                        }
+                    }
                 }
                 UFM_WREC(2, tot);
                 if (tot >= PPWK * max_sweeps && lane == 0)  // give up this visit; the tile is re-queued
@@ -1037,8 +1301,17 @@ __global__ __launch_bounds__(OWNK == 2 ? NTHR / 2 : NTHR, UFM_RELAX_WAVES) void 
                 if (bits && lane == 0) __hip_atomic_fetch_or(&s_wake[w], bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 if (lane == 0) atomicAdd(&s_idle, 1);
                 UFM_WREC(3, 0);
+                int polls = 0;
                 for (;;) {
                     __builtin_amdgcn_s_sleep(UFM_IDLE_SLEEP);
+                    ++polls;
+                    if constexpr (EARLY) {
+                        if (ew_pend && polls >= UFM_EARLY_POLLS) ew_flush();   // (the stores are ~1 us old by now: no wait)
+                        if (!(P.own_flags & 18)) {
+                            if (w < 4 && (polls & 31) == 8 + 4 * w) halo_poll();
+                            if (halo_refresh()) break;                         // (back to the wake bits: this wave is not idle any more)
+                        }
+                    }
                     if (__hip_atomic_load(&s_idle, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >= NWV ||
                         __hip_atomic_load(&s_giveup, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != 0) { vote = true; break; }
                     if (__hip_atomic_load(&s_wake[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != 0) {
@@ -1083,96 +1356,15 @@ __global__ __launch_bounds__(OWNK == 2 ? NTHR / 2 : NTHR, UFM_RELAX_WAVES) void 
         //  the tests below ahead of the tile loop and carries them through the sweeps -- registers the sweep loop needs)
         int wb_r = io_r, wb_c = io_c;
         asm volatile("" : "+v"(wb_r), "+v"(wb_c));
-        const float gf = io_on ? Gs[(wb_r + 1) * GP + wb_c + 1] : gl0;
-        if (gf != gl0) {
-            st_f<OWN>(&Gt[tid], gf);
-            {   // a border value also lives in the rings of the neighbours it borders
-                const int er_ = (wb_r == 0) ? -1 : ((wb_r == T - 1) ? 1 : 0);
-                const int ec_ = (wb_c == 0) ? -1 : ((wb_c == T - 1) ? 1 : 0);
-                const bool rok = er_ && tx + er_ >= 0 && tx + er_ < P.TX, cok = ec_ && ty + ec_ >= 0 && ty + ec_ < P.TY;
-                if (rok) st_f<OWN>(&P.ring[(size_t)(gt + er_ * P.TY) * RING + (er_ < 0 ? RING_BOT : RING_TOP) + wb_c], gf);
-                if (cok) st_f<OWN>(&P.ring[(size_t)(gt + ec_) * RING + (ec_ < 0 ? RING_RIGHT : RING_LEFT) + wb_r], gf);
-                if (rok && cok)   // my corner (er_, ec_) is the opposite corner of the diagonal neighbour's halo
-                    st_f<OWN>(&P.ring[(size_t)(gt + er_ * P.TY + ec_) * RING + RING_CORNER + (er_ < 0 ? 2 : 0) + (ec_ < 0 ? 1 : 0)], gf);
-            }
-            // DFM only: the float fixed point of the upwind quadratic is not unique (DESIGN.md section 6);
-            // neighbouring tiles can push each other's border values up one ulp at a time for tens of
-            // thousands of launches.  An INCREASE of at most 4 ulp (a rounding-level correction, never
-            // new information) is stored but does not wake the neighbour; after 24 visits of a tile in
-            // one step the same holds for decreases.  Well inside DFM's 1e-6 tolerance.
-            bool significant = true;
-            if (is_dfm<ALGO> && MODE == MODE_LOWER && gf < INFINITY && gl0 < INFINITY) {
-                const int du = __float_as_int(gf) - __float_as_int(gl0);
-                // (level 1: only in a tile that keeps coming back -- the rises of its operator are corrections of
-                //  values latched from transient neighbours and have to travel)
-                if (ALGO == UFM_ALGO_DFM ? (du > 0 ? du <= 4 : (s_misc[1] > UFM_DFM_QUIET_VISITS && du >= -4))
-                                         : (s_misc[1] > UFM_DFM1_QUIET_VISITS && du >= -4 && du <= 4)) significant = false;
-            }
-            // priority handed to a neighbour: the new value (lowering) / the value that was
-            // invalidated (raising: the reference's key of an under-consistent element, min(g,rhs) = g)
-            const int pb = __float_as_int((MODE == MODE_LOWER) ? gf : gl0);
-            const int er = (wb_r == 0) ? -1 : ((wb_r == T - 1) ? 1 : 0);
-            const int ec = (wb_c == 0) ? -1 : ((wb_c == T - 1) ? 1 : 0);
-            // Causality: every value the update operators produce is larger than each input it
-            // depends on (the interpolated cost-to-goal of the far edge plus a positive traversal
-            // cost), so an element h of a neighbour tile can neither be lowered by nor have been
-            // supported by a border value that is, before and after this visit, not below h: the
-            // wake-up -- half of all tile visits used to find nothing to do -- is skipped.  h is read
-            // from the halo as staged.  A neighbour that is being visited in this same launch only
-            // lowers its border meanwhile, which keeps the test conservative -- except for the
-            // ulp-level rises of replace semantics: a tile whose own border ROSE during a visit
-            // therefore comes back once more (s_bmin[4]) and re-reads its neighbours' borders.
-            bool need_r = true, need_c = true, need_d = true;
-            if (UFM_CAUSAL_FILTER && MODE == MODE_LOWER) {
-                const float lo = fminf(gf, gl0);
-                const int cl = max(wb_c - 1, 0) + 1, ch = min(wb_c + 1, T - 1) + 1;     // halo columns / rows that belong
-                const int rl = max(wb_r - 1, 0) + 1, rh = min(wb_r + 1, T - 1) + 1;     // to the edge neighbour itself
-                if (er) {
-                    const float *h = Gs + (wb_r + 1 + er) * GP;
-                    need_r = lo < fmaxf(fmaxf(h[cl], h[wb_c + 1]), h[ch]);
-                }
-                if (ec) {
-                    const int hc = wb_c + 1 + ec;
-                    need_c = lo < fmaxf(fmaxf(Gs[rl * GP + hc], Gs[(wb_r + 1) * GP + hc]), Gs[rh * GP + hc]);
-                }
-                if (er && ec) need_d = lo < Gs[(wb_r + 1 + er) * GP + wb_c + 1 + ec];
-                // Node planners, lowered value: sharper.  Whatever a neighbour's border node h can gain from this side
-                // comes over the row of cells between the two tiles, from the border nodes next to h: its new value
-                // would be at least (the smallest of those nodes) + (the cheaper of the two cells it touches on this side)
-                // x (one edge length).  (The nodes next to h in the halo belong to a third tile; if one of them is being
-                // lowered in this very launch, this tile sees its old value -- but then it is that tile's visit that
-                // holds the edge's cheaper end and makes the same test with the right number.)  A neighbour whose border already lies below that -- a front running beside
-                // this tile, a step ahead of it -- has nothing to gain and is not woken (41 % of the plan's tile visits
-                // found nothing to do with the test above alone).  Rises keep the test above: an ulp-level correction
-                // must reach whoever was computed from the old value.
-                if (UFM_STEP_FILTER && !is_dfm<ALGO> && gf < gl0) {
-                    const int crow_r = (er < 0) ? 0 : T;                   // cost row / column of the cells between the tiles
-                    const int ccol_c = (ec < 0) ? 0 : T;
-                    auto gain_r = [&](int hc) {                           // h = halo row, LDS column hc (node column hc - 1 of the tile)
-                        const float *mine = Gs + (wb_r + 1) * GP;          // my border row (new values)
-                        const float m3 = fminf(fminf(mine[hc - 1], mine[hc]), mine[hc + 1]);       // (halo columns included: a node of the tile beside
-                                                                                           //  this one can be the cheaper end of the edge)
-                        const float c2 = fminf(Cs[crow_r * CP + hc - 1], Cs[crow_r * CP + hc]);
-                        return Gs[(wb_r + 1 + er) * GP + hc] > m3 + c2;
-                    };
-                    auto gain_c = [&](int hr) {
-                        const int mc = wb_c + 1;
-                        const float m3 = fminf(fminf(Gs[(hr - 1) * GP + mc], Gs[hr * GP + mc]), Gs[(hr + 1) * GP + mc]);
-                        const float c2 = fminf(Cs[(hr - 1) * CP + ccol_c], Cs[hr * CP + ccol_c]);
-                        return Gs[hr * GP + mc + ec] > m3 + c2;
-                    };
-                    if (er && need_r) need_r = gain_r(cl) || gain_r(wb_c + 1) || gain_r(ch);
-                    if (ec && need_c) need_c = gain_c(rl) || gain_c(wb_r + 1) || gain_c(rh);
-                    if (er && ec && need_d) need_d = Gs[(wb_r + 1 + er) * GP + wb_c + 1 + ec] >
-                                                      fminf(gf, fminf(Gs[(wb_r + 1 + er) * GP + wb_c + 1], Gs[(wb_r + 1) * GP + wb_c + 1 + ec])) + Cs[crow_r * CP + ccol_c];
-                }
-                if ((er || ec) && significant && gf > gl0) atomicMin(&s_bmin[4], __float_as_int(gl0));
-            }
-            if (!conv) atomicMin(&s_bmin[4], pb);
-            if (er && significant && need_r) atomicMin(&s_bmin[(er + 1) * 3 + 1], pb);
-            if (ec && significant && need_c) atomicMin(&s_bmin[3 + ec + 1], pb);
-            if (er && ec && significant && need_d) atomicMin(&s_bmin[(er + 1) * 3 + ec + 1], pb);
+        const float gref = EARLY ? (io_on ? Os[tid] : 0.0f) : gl0;   // what HBM holds (early hand-off: as last written during the visit)
+        const float gf = io_on ? Gs[(wb_r + 1) * GP + wb_c + 1] : gref;
+        if (gf != gref) {
+            wb_store(wb_r, wb_c, gf);
+            wb_note(wb_r, wb_c, wb_need(wb_r, wb_c, gf, gref), gf, gref, s_bmin);
+            if (!conv) atomicMin(&s_bmin[4], __float_as_int((MODE == MODE_LOWER) ? gf : gref));
         }
+        // (early hand-off: what a wave has written out but not yet told the neighbours goes with the write-back's activations)
+        if constexpr (EARLY) if (tid < NWV * 9) { const int v = s_emin[tid]; if (v != INFBITS && tid % 9 != 4) atomicMin(&s_bmin[tid % 9], v); }
         // resident kernel: the values must have arrived -- and the next tile's mark -- before a neighbour is told
         if constexpr (OWN) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
@@ -1181,7 +1373,7 @@ __global__ __launch_bounds__(OWNK == 2 ? NTHR / 2 : NTHR, UFM_RELAX_WAVES) void 
             const int dr = tid / 3 - 1, dc = tid % 3 - 1;
             if (tid == 4) {
                 if (!conv || s_bmin[4] != INFBITS) {           // sweep cap hit / border rose: come back
-                    if (OWN) own_push(P, gt, min(s_bmin[4], INFBITS - 1));
+                    if (OWN) own_push(P, gt, min(s_bmin[4], INFBITS - 1), gt);
                     else activate(P, Q, k + 1, gt, min(s_bmin[4], INFBITS - 1));
                 }
                 P.hint[gt] = s_misc[3];
@@ -1194,7 +1386,7 @@ __global__ __launch_bounds__(OWNK == 2 ? NTHR / 2 : NTHR, UFM_RELAX_WAVES) void 
             } else if (s_bmin[tid] != INFBITS) {
                 const int ntx = tx + dr, nty = ty + dc;
                 if (ntx >= 0 && ntx < P.TX && nty >= 0 && nty < P.TY) {
-                    if (OWN) own_push(P, m * P.NTm + ntx * P.TY + nty, s_bmin[tid]);
+                    if (OWN) own_push(P, m * P.NTm + ntx * P.TY + nty, s_bmin[tid], gt);
                     else activate(P, Q, k + 1, m * P.NTm + ntx * P.TY + nty, s_bmin[tid]);
                 }
             }
@@ -1204,6 +1396,9 @@ __global__ __launch_bounds__(OWNK == 2 ? NTHR / 2 : NTHR, UFM_RELAX_WAVES) void 
             const int dbg_ninf1 = __syncthreads_count(io_on && gf == INFINITY);
             if (tid == 0) {
                 const unsigned long long tk3 = wall_clock64();
+                if (OWN && gt < TILE_DIAG_MAX && (!EARLY || (s_qw[1] & 0x10000))) g_tile[1][gt] = (unsigned int)(tk3 - g_tile_t0);
+                if (OWN && s_misc_vi < VIS_DIAG_MAX) g_vis[s_misc_vi][2] = (unsigned int)(tk3 - g_tile_t0);
+                if (EARLY) atomicAdd(&g_tdiag[6], (unsigned long long)(s_qw[1] & 0xFFFF));   // in-visit refreshes
                 atomicAdd(&g_tdiag[0], tk1 - tk0); atomicAdd(&g_tdiag[1], tk2 - tk1); atomicAdd(&g_tdiag[2], tk3 - tk2);
                 atomicAdd(&g_tdiag[3], 1ull);
                 const unsigned long long bin = (tk3 - tk0) / 200;
@@ -1461,6 +1656,14 @@ __device__ void unpark(const DevParams &P, int qz, int k, float rbound, int &s_k
 // The resident lowering kernel stands in for launch k of the lowering queue and everything after it: this kernel hands
 // it the entries of list k % 3 and does the list bookkeeping a launch does for its successors (k_relax, block 0) ...
 __global__ void k_own_import(DevParams P, int k) {
+#ifdef UFM_TIMING
+    if (blockIdx.x == 0 && threadIdx.x == 0) g_tile_t0 = wall_clock64();
+    for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < TILE_DIAG_MAX; t += gridDim.x * blockDim.x) {
+        g_tile[0][t] = 0xFFFFFFFFu; g_tile[1][t] = 0u; g_tile[2][t] = 0xFFFFFFFFu; g_tile[3][t] = 0u; g_tile[4][t] = 0u;
+        g_push64[t] = ~0ull;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) g_nvis = 0u;
+#endif
     const int r = k % 3, rz = (k + 2) % 3;
     const int n = P.ctr->cnt[Q_LOWER][r];
     const int *cand = P.cand + (size_t)(Q_LOWER * 3 + r) * P.NT;
@@ -1801,7 +2004,8 @@ struct Engine {
     uint32_t owned_launches = 0;
     hipEvent_t own_ev[2] = {nullptr, nullptr};
     bool own_timed = false;
-    int owned_flags = 0;
+    int owned_flags = 2;             // resident kernel, diagnostics and variants.  1: no tile taken ahead; 2: no early hand-off (FD / SG); 4: early hand-off once per patch and visit;
+                                     // 8: early hand-off waits for its stores inside the sweep loop; 16: no in-visit halo refresh
     int owned_waves = 0;             // waves per tile visit of the resident kernel: 16 (256 workgroups), 8 (512), 0 = by the size of the job
     bool use_region = true;          // replans: one workgroup runs both phases in LDS on the block around the patch (ufm_region.h);
                                      // the launch chain only takes over when work is left outside the block
@@ -3051,6 +3255,20 @@ int ufm_debug_trace(unsigned long long *out, int cap) {     // returns the numbe
     const unsigned int z = 0;
     hipMemcpyToSymbol(HIP_SYMBOL(g_ntrace), &z, sizeof(z));
     return (int)n;
+}
+int ufm_debug_visits(unsigned int *out, int cap) {   // out[cap][5]; returns the number of visits recorded
+    unsigned int n = 0;
+    if (hipMemcpyFromSymbol(&n, HIP_SYMBOL(g_nvis), sizeof(n)) != hipSuccess) return UFM_ERR_HIP_BASE;
+    if ((int)n > cap) n = cap;
+    if (n > VIS_DIAG_MAX) n = VIS_DIAG_MAX;
+    if (n && hipMemcpyFromSymbol(out, HIP_SYMBOL(g_vis), sizeof(unsigned int) * 5 * n) != hipSuccess) return UFM_ERR_HIP_BASE;
+    return (int)n;
+}
+int ufm_debug_tiles(unsigned int *out, int n) {     // out[5][n]
+    if (n > TILE_DIAG_MAX) n = TILE_DIAG_MAX;
+    for (int r = 0; r < 5; ++r)
+        if (hipMemcpyFromSymbol(out + (size_t)r * n, HIP_SYMBOL(g_tile), sizeof(unsigned int) * n, sizeof(unsigned int) * (size_t)r * TILE_DIAG_MAX) != hipSuccess) return UFM_ERR_HIP_BASE;
+    return n;
 }
 int ufm_debug_wtrace(unsigned long long *out, unsigned int *counts) {
     if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_wtrace), sizeof(unsigned long long) * 16 * 256 * 2) != hipSuccess) return UFM_ERR_HIP_BASE;
