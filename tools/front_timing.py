@@ -29,9 +29,14 @@ for kv in a.param:
 T = L.ufm_tile_edge()
 TX = TY = (a.size + 1 + T - 1) // T
 NT = TX * TY
+L.ufm_debug_sdiag.argtypes = [C.c_void_p, C.c_int]
 for rep in range(a.reps):
     p.set_map(cost); p.reset(); p.set_start(*start); p.set_goal(*goal)
+    L.ufm_debug_sdiag(None, 1)
     assert p.step() == 0
+sd = (C.c_ulonglong * 16)()
+L.ufm_debug_sdiag(sd, 0)
+print("looks of idle workgroups %d, nothing to take %d | helping: attempts %d, victim had a free queued tile %d, inside the band %d, taken %d | failed takes: ahead %d, fresh %d" % tuple(sd[i] for i in range(8)))
 buf = np.zeros((5, NT), np.uint32)
 assert L.ufm_debug_tiles(buf.ctypes.data, NT) == NT
 first, last, _, vis, wsum = [buf[i].astype(np.float64) for i in range(5)]
@@ -75,7 +80,7 @@ order = np.argsort(v_s)
 for i in order:
     by_tile.setdefault(int(v_gt[i]), []).append(int(i))
     by_own.setdefault(int(own[i]), []).append(int(i))
-cur = int(np.argmax(v_e))
+cur = int(np.argmax(np.where(v_from != 0xFFFFFFFF, v_e, 0)))     # (the last visit that took an activation somebody sent)
 links = []
 while True:
     f, pt = int(v_from[cur]), int(v_pt[cur])
@@ -86,24 +91,32 @@ while True:
         break
     pred = cands[-1]
     # how much of the wait was the owner busy with other tiles
-    busy = 0
+    busy = same = 0
     for i in by_own[int(own[cur])]:
         if i == cur:
             continue
         lo, hi = max(int(v_s[i]), pt), min(int(v_e[i]) if v_e[i] else int(v_s[i]), int(v_s[cur]))
         if hi > lo:
             busy += hi - lo
-    links.append((cur, pred, (int(v_s[cur]) - pt) / 100.0, (pt - int(v_s[pred])) / 100.0, busy / 100.0, (int(v_e[pred]) - int(v_s[pred])) / 100.0))
+    for i in by_tile[int(v_gt[cur])]:           # ... or the tile itself was still being visited (by whoever) when the activation came
+        if i == cur:
+            continue
+        lo, hi = max(int(v_s[i]), pt), min(int(v_e[i]) if v_e[i] else int(v_s[i]), int(v_s[cur]))
+        if hi > lo:
+            same += hi - lo
+    links.append((cur, pred, (int(v_s[cur]) - pt) / 100.0, (pt - int(v_s[pred])) / 100.0, busy / 100.0, (int(v_e[pred]) - int(v_s[pred])) / 100.0, same / 100.0))
     if pred == cur:
         break
     cur = pred
     if len(links) > 100000:
         break
-la = np.array([(w, sp, b, d) for (_c, _p, w, sp, b, d) in links])
+if not links:
+    sys.exit(0)
+la = np.array([(w, sp, b, d, sm) for (_c, _p, w, sp, b, d, sm) in links])
 print("critical path: %d links back from the last visit (ends %.0f us) to a visit starting at %.0f us" % (len(links), v_e.max() / 100.0, v_s[cur] / 100.0))
 print("  per link: activation sent %.1f us after the sender's visit began (its visit lasted %.1f us) + waited %.1f us for its own visit (owner busy with other tiles %.1f us of that)" % (
     la[:, 1].mean(), la[:, 3].mean(), la[:, 0].mean(), la[:, 2].mean()))
-print("  sums: in sender visits %.0f us, waiting %.0f us (owner busy %.0f us)" % (la[:, 1].sum(), la[:, 0].sum(), la[:, 2].sum()))
+print("  sums: in sender visits %.0f us, waiting %.0f us (owner busy %.0f us; the tile itself still in an earlier visit %.0f us)" % (la[:, 1].sum(), la[:, 0].sum(), la[:, 2].sum(), la[:, 4].sum()))
 print("  wait histogram (us) <2 <5 <10 <20 <40 <80 >=80: %s" % np.histogram(la[:, 0], bins=[-1e9, 2, 5, 10, 20, 40, 80, 1e9])[0])
 self_links = sum(1 for (c, p_, *_r) in links if v_gt[c] == v_gt[p_])
 print("  links where a tile re-queued itself: %d; distinct tiles on the path: %d" % (self_links, len(set(int(v_gt[c]) for (c, *_r) in links))))

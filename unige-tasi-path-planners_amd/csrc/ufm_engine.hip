@@ -210,6 +210,8 @@ struct DevParams {
     int *lmax;                  // [LMAX] diagnostics: per launch, the largest per-wave sweep count of any tile
     int *own_prio;              // [OWN_NW][own_slots] resident lowering kernel (k_relax<.,LOWER,false,1|2>): the queue, one word per tile, grouped
                                 // by the workgroup that owns the tile -- float bits of its priority, >= INFBITS = not queued (see own_push)
+    int *own_lock;              // [OWN_NW][own_slots] 1 while the tile is being visited: whoever takes a tile (its owner, or an idle workgroup helping
+                                // out) needs both the queue word AND this lock -- an activation that lands during a visit re-queues the tile at once
     int *own_min;               // [OWN_NW] smallest priority each owner holds (queued or in flight): a hint for the ordering band, not exact
     unsigned long long own_limit;   // wall-clock ticks (100 MHz) after which the resident kernel hands back to the launch chain
     int own_flags;              // diagnostics: 1 = no tile taken ahead (every visit starts with a fresh look at the queue)
@@ -299,14 +301,15 @@ __device__ __forceinline__ float tile_heuristic(const DevParams &P, int m, int t
 // (tx, ty) with (tx mod 16, ty mod 16) = its index -- any stretch of a front is spread over all of them.  A tile's
 // queue entry is ONE word that only its owner ever removes:
 //     key (< INFBITS)  queued with that priority          -- neighbours lower it with atomicMin, fire and forget
-//     OWN_MARK         being visited by its owner         -- an atomicMin of a key re-queues it meanwhile
+//     OWN_MARK + w     being visited by workgroup w        -- an atomicMin of a key re-queues it meanwhile
 //     other >= INFBITS empty (INFBITS + 1 + a per-owner visit count: the word never returns to an earlier empty value)
 // so a tile is never visited twice at once, no list is appended to and no cursor is shared.  The owner resets
 // MARK -> empty only after the activations of that visit have been performed: the words of all owners are non-empty
 // as long as anything is queued, in flight, or about to be queued, and two identical all-empty collects of them in a
 // row mean the phase is over (an empty value never repeats, so identical collects are a true snapshot).
 constexpr int OWN_NW = 512;    // most owners a launch of the resident kernel has (P.own_nw: 256 or 512)
-constexpr int OWN_MARK = 0x7FFFFFFF;
+constexpr int OWN_MARK = 0x7FFFFE00;     // + the visiting workgroup (< OWN_NW): a visitor takes back its own mark only
+constexpr unsigned int OWN_EMPTIES = 0x7FFDFEu;   // empty values: INFBITS + 1 + (0 .. OWN_EMPTIES - 1), all below the marks
 __device__ __forceinline__ void own_locate(const DevParams &P, int gt, int &o, int &s) {
     const int m = gt / P.NTm, t = gt - m * P.NTm, tx = t / P.TY, ty = t - tx * P.TY;
     o = ((tx & 15) << P.own_ys) | (ty & ((1 << P.own_ys) - 1));
@@ -326,6 +329,8 @@ __device__ __forceinline__ int own_tile(const DevParams &P, int o, int s, int &m
 constexpr int TILE_DIAG_MAX = 1 << 19;
 __device__ unsigned int g_tile[5][TILE_DIAG_MAX];
 __device__ unsigned long long g_tile_t0;
+__device__ unsigned long long g_sdiag[16];   // looks of idle workgroups: [0] looks, [1] with nothing to take, [2] helping attempts, [3] a victim's word found,
+                                             // [4] inside the band, [5] taken, [6] takes ahead that failed, [7] fresh takes that failed
 // ... and the visits themselves, for the critical path: {tile, start, end, earliest activation taken: time, tile that sent it}
 constexpr int VIS_DIAG_MAX = 1 << 20;
 __device__ unsigned long long g_push64[TILE_DIAG_MAX];     // per tile: {time, sender} of the earliest activation not yet taken
@@ -649,7 +654,9 @@ __global__ __launch_bounds__(OWNK == 2 ? NTHR / 2 : NTHR, UFM_RELAX_WAVES) void 
     // resident kernel, node planners: border values are handed to the neighbours DURING the visit (early hand-off, below):
     // Os = what HBM holds for every element of the tile (as staged, then as last written), s_emin = per wave and direction the
     // smallest border value an early write has changed
-    constexpr bool EARLY = OWN && UFM_EARLY_HANDOFF && !is_dfm<ALGO>;
+    // (16 waves per visit only: with 8 waves and two visits per CU -- the form for jobs that are bound by the number of visits, not by
+    //  their chain -- the longer visits cost more than the saved ones bring: 8192^2 plan 41.3 -> 44.0 ms)
+    constexpr bool EARLY = OWNK == 1 && UFM_EARLY_HANDOFF && !is_dfm<ALGO>;
     __shared__ float Os[EARLY ? TT : 1];
     __shared__ int s_emin[EARLY ? 16 * 9 : 1];
 #ifdef UFM_TIMING
@@ -719,9 +726,11 @@ __global__ __launch_bounds__(OWNK == 2 ? NTHR / 2 : NTHR, UFM_RELAX_WAVES) void 
     bool first_pop = UFM_STATIC_FIRST;
     if (tid == 4) { s_stat[0] = 0ull; s_stat[1] = 0ull; s_stat[2] = 0ull; }   // (thread 4 alone reads and writes them)
     int st_lmax = 0;
-    // resident kernel: this workgroup's queue words; own_prev = slot of a finished visit whose "being visited" mark is still
-    // to be taken back; own_next = slot taken (marked) for the next visit while the current one was being written back
+    // resident kernel: this workgroup's queue words.  Slots are kept as indices into the whole array of words (owner * own_slots + slot),
+    // because an idle workgroup also takes tiles of other owners (below).  s_own[0] = word of a finished visit whose "being visited" mark
+    // is still to be taken back; own_next = word taken (marked) for the next visit while the current one was being written back
     int *const own_q = OWN ? P.own_prio + (size_t)blockIdx.x * P.own_slots : nullptr;
+    const int own_base = OWN ? (int)blockIdx.x * P.own_slots : 0;
     int own_next = -1, own_slot_now = -1;   // (the same in every thread)
     const unsigned long long own_t0 = OWN ? wall_clock64() : 0ull;
     if (OWN && tid == 0) { s_own[0] = -1; s_own[1] = -1; s_own[2] = 0; s_late = 0; }
@@ -756,28 +765,112 @@ __global__ __launch_bounds__(OWNK == 2 ? NTHR / 2 : NTHR, UFM_RELAX_WAVES) void 
         if (lane == 0 && ba) atomicOr(&s_gmin, bb ? 3 : 1);
         lds_barrier();
     };
+    // An "empty" value no word has held before in this launch (the end-of-phase test relies on it): visit count x workgroup.  (A workgroup
+    // that runs out of values -- 16 k of them -- leaves like one that runs out of time.)
+    auto own_empty = [&]() -> int {
+        const unsigned int c = (unsigned int)s_own[2]++;
+        return INFBITS + 1 + (int)((c * (unsigned int)OWN_NW + blockIdx.x) % OWN_EMPTIES);
+    };
+    // Taking a tile (thread 0): the queue word goes from the priority it was seen with to this workgroup's mark (compare-and-swap: a mark
+    // or an empty value of somebody else is never overwritten) and the tile's lock from 0 to 1 -- two atomics issued together, looked
+    // at together.  With both, the tile is this workgroup's until own_release().  With the activation but not the lock (the tile is
+    // being visited: the activation landed during that visit) the activation goes back into the word; with the lock but no
+    // activation (the word had changed since it was looked at) the lock is released.
+    auto own_take_issue = [&](int gw, int prio, int &r_old, int &r_lk) {
+        int expect = prio;
+        __hip_atomic_compare_exchange_strong(&P.own_prio[gw], &expect, OWN_MARK + (int)blockIdx.x, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        r_old = expect;
+        r_lk = __hip_atomic_exchange(&P.own_lock[gw], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    };
+    auto own_take_resolve = [&](int gw, int &prio, int r_old, int r_lk) -> bool {
+        bool got = r_old == prio;
+        if (!got && r_lk == 0 && r_old < prio) {   // still queued, only lower meanwhile (the word was chosen from an older copy): once more
+            int expect = r_old;
+            got = __hip_atomic_compare_exchange_strong(&P.own_prio[gw], &expect, OWN_MARK + (int)blockIdx.x, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (got) prio = r_old;
+        }
+        if (got && r_lk == 0) return true;
+        if (got) __hip_atomic_fetch_min(&P.own_prio[gw], prio, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);          // (mark -> queued again)
+        else if (r_lk == 0) __hip_atomic_store(&P.own_lock[gw], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return false;
+    };
     // thread 0, after a decision: take back the mark of the visit before the last (its activations have long been performed),
-    // say what this workgroup holds, mark the chosen tile.  The exchange is not waited for here.
-    auto own_commit = [&](unsigned long long b, bool take, bool wait) -> int {   // wait: that visit's activations have only just been issued
+    // say what this workgroup holds, mark the chosen tile.  The atomics of the take are not waited for here.
+    auto own_commit = [&](unsigned long long b, bool take, bool wait, int &r_old, int &r_lk) {   // wait: that visit's activations have only just been issued
         const int own_prev = s_own[0];
         if (own_prev >= 0) {
             if (wait) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            int expect = OWN_MARK;
-            __hip_atomic_compare_exchange_strong(&own_q[own_prev], &expect, INFBITS + 1 + (s_own[2] & 0x3FFFFF),
-                                                 __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            int expect = OWN_MARK + (int)blockIdx.x;
+            __hip_atomic_compare_exchange_strong(&P.own_prio[own_prev], &expect, own_empty(), __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             s_own[0] = -1;
         }
         __hip_atomic_store(&P.own_min[blockIdx.x], b != ~0ull ? (int)(b >> 32) : INFBITS, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        int was = INFBITS;
-        if (take) {
-            s_own[2] += 1;
-            was = __hip_atomic_exchange(&own_q[(int)(unsigned int)b], OWN_MARK, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (take) own_take_issue(own_base + (int)(unsigned int)b, (int)(b >> 32), r_old, r_lk);
+    };
+    // An idle workgroup helps out.  Ownership spreads a front over the workgroups only on average: the critical path of a 4096^2 plan
+    // (tools/front_timing.py) is ~330 visits long, and on it an activation waits 45 us for its visit -- 31 us of them while its owner
+    // is busy with other tiles, next to workgroups that find nothing of their own inside the band.  So a workgroup with nothing to take
+    // looks at the owner that holds the smallest priority (the hints), at that owner's words, and takes its best queued tile if
+    // that lies inside the ordering band -- by the same take the owner uses (own_take_issue), so a tile still has one visitor at a time.
+    // All threads call; returns the word taken (its priority in s_own[3]) or -1.
+    int steal_seq = 0;
+    auto own_steal = [&](int hint) -> int {
+        unsigned long long hk = hint != INFBITS ? (((unsigned long long)(unsigned int)hint << 32) | (unsigned int)tid) : ~0ull;
+        for (int o_ = 32; o_; o_ >>= 1) hk = min(hk, (unsigned long long)__shfl_xor((long long)hk, o_));
+        if (tid == 0) { s_best = ~0ull; s_gmin = -1; }
+        lds_barrier();
+        if (lane == 0 && hk != ~0ull) atomicMin(&s_best, hk);
+        lds_barrier();
+        const unsigned long long vk = s_best;
+        lds_barrier();
+#ifdef UFM_TIMING
+        if (tid == 0) atomicAdd(&g_sdiag[2], 1ull);
+#endif
+        if (vk == ~0ull) return -1;
+        // (whose words: not the holder of the smallest priority -- its best tile is as a rule the one it is visiting, and every idle
+        //  workgroup would go for the same word -- but a different owner at every look; the smallest hint is the floor of the band)
+        ++steal_seq;
+        const int vo = ((int)blockIdx.x + 1 + (int)((unsigned int)(steal_seq * 61 + (int)blockIdx.x * 17) % (unsigned int)(P.own_nw - 1))) % P.own_nw;
+        const int *vq = P.own_prio + (size_t)vo * P.own_slots;
+        unsigned long long bb = ~0ull;
+#pragma unroll 1
+        for (int sl = tid; sl < P.own_slots; sl += NTH) {
+            const int v = __hip_atomic_load(&vq[sl], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const int lk = __hip_atomic_load(&P.own_lock[(size_t)vo * P.own_slots + sl], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (v < INFBITS && lk == 0) bb = min(bb, ((unsigned long long)(unsigned int)v << 32) | (unsigned int)sl);
         }
-        return was;   // the priority the tile was queued with (on its way: not waited for here)
+        for (int o_ = 32; o_; o_ >>= 1) bb = min(bb, (unsigned long long)__shfl_xor((long long)bb, o_));
+        if (tid == 0) s_best = ~0ull;
+        lds_barrier();
+        if (lane == 0 && bb != ~0ull) atomicMin(&s_best, bb);
+        lds_barrier();
+        if (tid == 0) {
+            const unsigned long long b2 = s_best;
+#ifdef UFM_TIMING
+            if (b2 != ~0ull) atomicAdd(&g_sdiag[3], 1ull);
+            if (b2 != ~0ull && !(__int_as_float((int)(b2 >> 32)) > __int_as_float((int)(vk >> 32)) + delta)) atomicAdd(&g_sdiag[4], 1ull);
+#endif
+            if (b2 != ~0ull && !(__int_as_float((int)(b2 >> 32)) > __int_as_float((int)(vk >> 32)) + delta)) {
+                const int gw = vo * P.own_slots + (int)(unsigned int)b2;
+                int pr = (int)(b2 >> 32);
+                int r_old, r_lk;
+                own_take_issue(gw, pr, r_old, r_lk);
+                if (own_take_resolve(gw, pr, r_old, r_lk)) {
+                    s_own[3] = pr; s_gmin = gw;
+#ifdef UFM_TIMING
+                    atomicAdd(&g_sdiag[5], 1ull);
+#endif
+                    __hip_atomic_fetch_min(&P.own_min[blockIdx.x], pr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // what this workgroup holds now
+                }
+            }
+        }
+        __syncthreads();
+        return s_gmin;
     };
     for (int i = blockIdx.x;; i += gridDim.x) {
         int gt_own = -1;
         if constexpr (OWN) {
+            if (own_next >= 0 && s_own[3] >= INFBITS) own_next = -1;   // chosen ahead from the older copy of the words, but the take failed
             if (tid == 0 && s_own[1] >= 0) { s_own[0] = s_own[1]; s_own[1] = -1; }   // (at most one mark waits: own_commit ran since)
             while (own_next < 0) {                             // nothing was taken ahead: look, wait, look again
                 __syncthreads();                               // LDS of the previous visit / round is free
@@ -805,7 +898,7 @@ __global__ __launch_bounds__(OWNK == 2 ? NTHR / 2 : NTHR, UFM_RELAX_WAVES) void 
 #pragma unroll 1
                         for (int e = tid; e < total; e += NTH) {
                             const int v = __hip_atomic_load(&P.own_prio[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                            if (v < INFBITS || v == OWN_MARK) mine_ok = false;
+                            if (v < INFBITS || v >= OWN_MARK) mine_ok = false;
                             acc += ((unsigned long long)(unsigned int)v + 1ull) * (0x9E3779B97F4A7C15ull + 2ull * (unsigned long long)e);
                         }
                         for (int o_ = 32; o_; o_ >>= 1) acc += (unsigned long long)__shfl_xor((long long)acc, o_);
@@ -819,21 +912,39 @@ __global__ __launch_bounds__(OWNK == 2 ? NTHR / 2 : NTHR, UFM_RELAX_WAVES) void 
                     int flag = 0;
                     // hand back to the launch chain (k_own_export): never stay for ever -- and not alone: a workgroup that only became
                     // resident when the others had left (the device was shared) must not wait out a limit of its own
-                    const bool late = !stop && (aborted || wall_clock64() - own_t0 > P.own_limit);
+                    const bool late = !stop && (aborted || wall_clock64() - own_t0 > P.own_limit || s_own[2] > 16000);
                     if (late) { atomicAdd(&P.ctr->own_stops, 1); __hip_atomic_store(&P.ctr->own_abort, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-                    s_own[3] = own_commit(b, take && !stop && !late, true);   // (waits for the exchange: the visit's loads must not overtake
-                    if (stop || late) flag = -1;                              //  it -- an activation it removes has to be one whose values
-                    else if (take) flag = 1;                                  //  the visit then sees)
+                    const bool taking = take && !stop && !late;
+                    int r_old = INFBITS, r_lk = 1;
+                    own_commit(b, taking, true, r_old, r_lk);
+                    // (the take is waited for: the visit's loads must not overtake it -- an activation it removes has to be one whose
+                    //  values the visit then sees)
+                    int pr = (int)(b >> 32);
+                    const bool got = taking && own_take_resolve(own_base + (int)(unsigned int)b, pr, r_old, r_lk);
+                    s_own[3] = got ? pr : INFBITS;
+#ifdef UFM_TIMING
+                    atomicAdd(&g_sdiag[0], 1ull);
+                    if (!taking) atomicAdd(&g_sdiag[1], 1ull);
+                    if (taking && !got) atomicAdd(&g_sdiag[7], 1ull);
+#endif
+                    if (stop || late) flag = -1;
+                    else if (got) flag = 1;
                     s_gmin = flag;
                 }
                 __syncthreads();
                 const int flag = s_gmin;
-                if (flag > 0) own_next = __builtin_amdgcn_readfirstlane((int)(unsigned int)b);
+                if (flag > 0) own_next = own_base + __builtin_amdgcn_readfirstlane((int)(unsigned int)b);
                 if (flag < 0) break;
-                if (flag == 0) __builtin_amdgcn_s_sleep(32);
+                if (flag == 0) {
+                    __syncthreads();                           // (s_gmin is used again)
+                    int got = -1;
+                    if ((votes & 1) && !(P.own_flags & 32)) got = own_steal(hint);
+                    if (got >= 0) own_next = __builtin_amdgcn_readfirstlane(got);
+                    else __builtin_amdgcn_s_sleep(32);
+                }
             }
             if (own_next < 0) break;
-            { int m_, tx_, ty_; gt_own = own_tile(P, blockIdx.x, own_next, m_, tx_, ty_); }
+            { const int o_ = own_next / P.own_slots; int m_, tx_, ty_; gt_own = own_tile(P, o_, own_next - o_ * P.own_slots, m_, tx_, ty_); }
             if (tid == 0) s_own[1] = own_next;
             own_slot_now = own_next;
             own_next = -1;
@@ -919,6 +1030,7 @@ __global__ __launch_bounds__(OWNK == 2 ? NTHR / 2 : NTHR, UFM_RELAX_WAVES) void 
             s_misc[0] = first; s_misc[1] = seen; s_misc[2] = 0; s_misc[3] = 0; s_idle = 0; s_giveup = 0;
         }
         if (tid < NWV) s_wake[tid] = (1 << PPWK) - 1;
+        bool own_parked = false;      // (thread 0)
         if constexpr (OWN) if (focused && w == 0) {
             // End condition: a tile whose priority lies beyond its map's start key (start_bound(): the largest key among the
             // start elements that have been reached) is not relaxed -- it goes to the park list of the launch chain, the
@@ -933,6 +1045,7 @@ __global__ __launch_bounds__(OWNK == 2 ? NTHR / 2 : NTHR, UFM_RELAX_WAVES) void 
                 if (!(__int_as_float(kb) + tile_heuristic(P, m, tx, ty) < B || B == INFINITY)) {
                     for (int j = 0; j < NWV; ++j) s_wake[j] = 0;
                     park_tile(P, Q_LOWER, gt, kb);
+                    own_parked = true;
                 }
             }
         }
@@ -956,7 +1069,7 @@ __global__ __launch_bounds__(OWNK == 2 ? NTHR / 2 : NTHR, UFM_RELAX_WAVES) void 
             const int c = (e == tid) ? c0 : ct[e];
             Cs[cr * CP + cc] = (cx < 0 || cy < 0 || cx >= P.L || cy >= P.W || c >= thr) ? INFINITY : (float)c;
         }
-        if constexpr (EARLY) { if (io_on) Os[tid] = gl0; if (tid < NWV * 9) s_emin[tid] = INFBITS; if (tid == 0) { s_qw[0] = OWN_MARK; s_qw[1] = 0; } }
+        if constexpr (EARLY) { if (io_on) Os[tid] = gl0; if (tid < NWV * 9) s_emin[tid] = INFBITS; if (tid == 0) { s_qw[0] = OWN_MARK; s_qw[1] = own_parked ? 0x20000 : 0; } }
         __syncthreads();
         UFM_TICK(tk1);
 #ifdef UFM_TIMING
@@ -1148,11 +1261,11 @@ __global__ __launch_bounds__(OWNK == 2 ? NTHR / 2 : NTHR, UFM_RELAX_WAVES) void 
         auto halo_poll = [&]() {
             typedef __attribute__((address_space(3))) void *lds_ptr;
             typedef const __attribute__((address_space(1))) void *glb_ptr;
-            if (lane == 0) __builtin_amdgcn_global_load_lds((glb_ptr)(own_q + own_slot_now), (lds_ptr)s_qw, 4, 0, 16);
+            if (lane == 0) __builtin_amdgcn_global_load_lds((glb_ptr)(P.own_prio + own_slot_now), (lds_ptr)s_qw, 4, 0, 16);
         };
         auto halo_refresh = [&]() -> bool {      // true: this wave did a refresh (it has left the idle count meanwhile)
             int seen = __hip_atomic_load(&s_qw[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            if (seen == OWN_MARK) return false;
+            if (seen >= INFBITS) return false;           // (still my mark)
             int mine = 0;
             if (lane == 0) mine = atomicCAS(&s_qw[0], seen, OWN_MARK) == seen;
             if (!__builtin_amdgcn_readfirstlane(mine)) return false;
@@ -1161,10 +1274,11 @@ __global__ __launch_bounds__(OWNK == 2 ? NTHR / 2 : NTHR, UFM_RELAX_WAVES) void 
             if (lane == 0 && gt < TILE_DIAG_MAX) atomicExch(&g_tile[2][gt], 0xFFFFFFFFu);
 #endif
             int was = OWN_MARK;
-            if (lane == 0) was = __hip_atomic_exchange(&own_q[own_slot_now], OWN_MARK, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (lane == 0) was = __hip_atomic_exchange(&P.own_prio[own_slot_now], OWN_MARK + (int)blockIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             was = __builtin_amdgcn_readfirstlane(was);
             if (was < INFBITS) {                 // (an activation: its values were stored before it was queued)
+                if (lane == 0) atomicMin(&s_emin[w * 9 + 4], was);   // (its priority counts for the tile's own, should the visit end at the sweep cap)
                 int t_ = tid;
                 asm volatile("" : "+v"(t_));
                 const int l_ = t_ & 63;
@@ -1285,7 +1399,10 @@ __global__ __launch_bounds__(OWNK == 2 ? NTHR / 2 : NTHR, UFM_RELAX_WAVES) void 
                             if (__builtin_amdgcn_ballot_w64(need != 0) != 0ull) {        // (a neighbour has something to gain: otherwise nothing is written)
                                 int *bm = s_emin + w_ * 9;
                                 ew_done |= 1 << j;
-                                if (chg) { Os[lx * T + ly] = g; wb_store(lx, ly, g); wb_note(lx, ly, need, g, o, bm); }
+                                if (chg) {
+                                    Os[lx * T + ly] = g; wb_store(lx, ly, g); wb_note(lx, ly, need, g, o, bm);
+                                    atomicMin(&bm[4], __float_as_int(g));     // (the tile's own priority, should the visit end at the sweep cap)
+                                }
                                 if (P.own_flags & 8) ew_flush();     // (variant: wait for the stores here, in the sweep loop)
                                 else ew_pend = 1;                    // the queue words follow when the wave has nothing to sweep (idle loop)
                             }
@@ -1307,7 +1424,9 @@ __global__ __launch_bounds__(OWNK == 2 ? NTHR / 2 : NTHR, UFM_RELAX_WAVES) void 
                     ++polls;
                     if constexpr (EARLY) {
                         if (ew_pend && polls >= UFM_EARLY_POLLS) ew_flush();   // (the stores are ~1 us old by now: no wait)
-                        if (!(P.own_flags & 18)) {
+                        // (not in a visit that ended at the end condition: an activation taken back there -- its priority may lie below
+                        //  the start's key -- would be lost with the sweeps that visit does not make)
+                        if (!(P.own_flags & 18) && !(__hip_atomic_load(&s_qw[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) & 0x20000)) {
                             if (w < 4 && (polls & 31) == 8 + 4 * w) halo_poll();
                             if (halo_refresh()) break;                         // (back to the wake bits: this wave is not idle any more)
                         }
@@ -1337,19 +1456,20 @@ __global__ __launch_bounds__(OWNK == 2 ? NTHR / 2 : NTHR, UFM_RELAX_WAVES) void 
         __syncthreads();
         UFM_TICK(tk2);
 
-        int own_was = INFBITS;
+        int own_ro = INFBITS, own_rl = 1;     // thread 0: what the two atomics of the take ahead returned (looked at after the write-back)
         if constexpr (OWN) {
             // The next tile is chosen and marked now, from the queue words as they were when this visit began to sweep: the
             // exchange is on its way while this visit is written back, and the next visit's loads follow the write-back with no
             // queue round trip in between.  (A fresh look costs two round trips in a row -- words, then exchange -- per visit.)
-            own_decide(tid < P.own_slots ? s_pf[tid] : INFBITS, (tid < P.own_nw && tid != (int)blockIdx.x) ? s_pfh[tid] : INFBITS, own_slot_now);
+            own_decide(tid < P.own_slots ? s_pf[tid] : INFBITS, (tid < P.own_nw && tid != (int)blockIdx.x) ? s_pfh[tid] : INFBITS,
+                       (own_slot_now >= own_base && own_slot_now < own_base + P.own_slots) ? own_slot_now - own_base : -1);
             const unsigned long long b = s_best;
             const bool take = b != ~0ull && !(s_gmin & 2) && !(P.own_flags & 1) && !s_late;
             if (tid == 0) {
-                own_was = own_commit(b, take, false);
-                if (wall_clock64() - own_t0 > P.own_limit) s_late = 1;   // (a workgroup that is never out of work looks at the clock here)
+                own_commit(b, take, false, own_ro, own_rl);
+                if (wall_clock64() - own_t0 > P.own_limit || s_own[2] > 16000) s_late = 1;   // (a workgroup that is never out of work looks at the clock here)
             }
-            own_next = __builtin_amdgcn_readfirstlane(take ? (int)(unsigned int)b : -1);
+            own_next = __builtin_amdgcn_readfirstlane(take ? own_base + (int)(unsigned int)b : -1);
         }
         // write back what changed; note which neighbours saw their halo change
         // (this thread's row and column, made opaque once per visit: the compiler otherwise computes the two dozen LDS addresses of
@@ -1364,11 +1484,23 @@ __global__ __launch_bounds__(OWNK == 2 ? NTHR / 2 : NTHR, UFM_RELAX_WAVES) void 
             if (!conv) atomicMin(&s_bmin[4], __float_as_int((MODE == MODE_LOWER) ? gf : gref));
         }
         // (early hand-off: what a wave has written out but not yet told the neighbours goes with the write-back's activations)
-        if constexpr (EARLY) if (tid < NWV * 9) { const int v = s_emin[tid]; if (v != INFBITS && tid % 9 != 4) atomicMin(&s_bmin[tid % 9], v); }
+        // (... and the smallest value written out early counts for the tile's own priority when the visit ended at the sweep cap, like
+        //  every other value the visit changed)
+        if constexpr (EARLY) if (tid < NWV * 9) { const int v = s_emin[tid]; if (v != INFBITS && (tid % 9 != 4 || !conv)) atomicMin(&s_bmin[tid % 9], v); }
         // resident kernel: the values must have arrived -- and the next tile's mark -- before a neighbour is told
-        if constexpr (OWN) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if constexpr (OWN) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (tid == 0) {
+                int pr = (int)(s_best >> 32);                    // (own_decide's choice: nobody has touched s_best since)
+                s_own[3] = (own_next >= 0 && own_take_resolve(own_next, pr, own_ro, own_rl)) ? pr : INFBITS;
+#ifdef UFM_TIMING
+                if (own_next >= 0 && s_own[3] >= INFBITS) atomicAdd(&g_sdiag[6], 1ull);
+#endif
+            }
+        }
         __syncthreads();
-        if (OWN && tid == 0) s_own[3] = own_was;
+        // the tile is free again: its values are in HBM (an activation that landed meanwhile has re-queued it already)
+        if (OWN && tid == 9) __hip_atomic_store(&P.own_lock[own_slot_now], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (tid < 9) {
             const int dr = tid / 3 - 1, dc = tid % 3 - 1;
             if (tid == 4) {
@@ -1686,6 +1818,7 @@ __global__ void k_own_export(DevParams P, int k1) {
     const int total = P.own_nw * P.own_slots;
     for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
         const int v = P.own_prio[e];
+        P.own_lock[e] = 0;
         if (v == INFBITS) continue;
         P.own_prio[e] = INFBITS;
         if (v < INFBITS) {
@@ -2004,8 +2137,8 @@ struct Engine {
     uint32_t owned_launches = 0;
     hipEvent_t own_ev[2] = {nullptr, nullptr};
     bool own_timed = false;
-    int owned_flags = 2;             // resident kernel, diagnostics and variants.  1: no tile taken ahead; 2: no early hand-off (FD / SG); 4: early hand-off once per patch and visit;
-                                     // 8: early hand-off waits for its stores inside the sweep loop; 16: no in-visit halo refresh
+    int owned_flags = 0;             // resident kernel, diagnostics and variants.  1: no tile taken ahead; 2: no early hand-off (FD / SG); 4: early hand-off once per patch and visit;
+                                     // 8: early hand-off waits for its stores inside the sweep loop; 16: no in-visit halo refresh; 32: idle workgroups do not help out
     int owned_waves = 0;             // waves per tile visit of the resident kernel: 16 (256 workgroups), 8 (512), 0 = by the size of the job
     bool use_region = true;          // replans: one workgroup runs both phases in LDS on the block around the patch (ufm_region.h);
                                      // the launch chain only takes over when work is left outside the block
@@ -2102,7 +2235,7 @@ void Engine::release() {
     std::memset(&graph_sig, 0, sizeof(graph_sig));
     void *ptrs[] = {P.G, P.Gprev, P.ring, P.cost, P.costT, P.goal, P.cand, P.ready, P.hint, P.rank, P.park, P.pflag, P.pprio,
                     P.queued, P.prio, P.start, P.bnd, P.dyn, P.spos, P.touched, P.fresh, P.tlist, P.sflag, P.slist, P.slist2,
-                    P.mark, P.num_updated, P.consume, P.lmax, P.own_prio, P.own_min, P.ctr, d_scratch};
+                    P.mark, P.num_updated, P.consume, P.lmax, P.own_prio, P.own_lock, P.own_min, P.ctr, d_scratch};
     for (void *q : ptrs) if (q) hipFree(q);
     P = DevParams{};                     // every pointer null again: a failed alloc() can be released, and released twice
     d_scratch = nullptr;
@@ -2168,6 +2301,7 @@ int Engine::alloc(int width, int length) {
     dmalloc(P.consume, sizeof(int) * nmaps);
     dmalloc(P.lmax, sizeof(int) * LMAX);
     dmalloc(P.own_prio, sizeof(int) * own_words());
+    dmalloc(P.own_lock, sizeof(int) * own_words());
     dmalloc(P.own_min, sizeof(int) * OWN_NW);
     dmalloc(P.ctr, sizeof(DevCounters));
     dmalloc(d_scratch, sizeof(int) * (4 * nmaps + 4));
@@ -2206,6 +2340,7 @@ int Engine::reset_queues() {
     HIPCHK(hipMemsetAsync(P.pflag, 0, sizeof(int) * 2 * P.NT, stream));
     k_fill<<<64, 256, 0, stream>>>(reinterpret_cast<float *>(P.pprio), (size_t)2 * P.NT, INFINITY);
     k_fill<<<64, 256, 0, stream>>>(reinterpret_cast<float *>(P.own_prio), own_words(), INFINITY);   // (+inf = INFBITS: empty)
+    HIPCHK(hipMemsetAsync(P.own_lock, 0, sizeof(int) * own_words(), stream));
     k_fill<<<2, 256, 0, stream>>>(reinterpret_cast<float *>(P.own_min), (size_t)OWN_NW, INFINITY);
     // the queue state at the head of DevCounters: cnt, rel, lmin, npark, nready, rcursor, nshort, last_work, fin_blocks
     static_assert(offsetof(DevCounters, cnt) == 0, "queue state leads the counter block");
@@ -2995,6 +3130,7 @@ int engine_create(Engine **out, int n_maps, int algo, int opt_lvl, int use_heuri
     // twice the sweeps per tile; a wider band and an earlier re-queue suit it better (plan 60 -> 52 ms)
     // -- for a single map; a batch is throughput-bound and keeps the less redundant setting (8 x 2048^2: 484 vs 476 M cells/s)
     if (algo == UFM_ALGO_DFM && n_maps == 1) { e->delta_scale = e->delta_scale_long = 2.5f; e->max_iters = 16; }
+    if (const char *dbg = std::getenv("UFM_OWNED_FLAGS")) e->owned_flags = std::atoi(dbg);   // (diagnostics: the same as ufm_set_param("owned_flags", .))
     e->maps.resize(n_maps);
     hipDeviceProp_t prop;
     HIPCHK(hipGetDeviceProperties(&prop, device_id));
@@ -3263,6 +3399,11 @@ int ufm_debug_visits(unsigned int *out, int cap) {   // out[cap][5]; returns the
     if (n > VIS_DIAG_MAX) n = VIS_DIAG_MAX;
     if (n && hipMemcpyFromSymbol(out, HIP_SYMBOL(g_vis), sizeof(unsigned int) * 5 * n) != hipSuccess) return UFM_ERR_HIP_BASE;
     return (int)n;
+}
+int ufm_debug_sdiag(unsigned long long *out, int reset) {
+    if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(g_sdiag), sizeof(unsigned long long) * 16) != hipSuccess) return UFM_ERR_HIP_BASE;
+    if (reset) { unsigned long long z[16] = {}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_sdiag), z, sizeof(z)) != hipSuccess) return UFM_ERR_HIP_BASE; }
+    return UFM_OK;
 }
 int ufm_debug_tiles(unsigned int *out, int n) {     // out[5][n]
     if (n > TILE_DIAG_MAX) n = TILE_DIAG_MAX;
