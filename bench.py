@@ -240,6 +240,8 @@ def run_rank(args):
         planner.set_occupancy_threshold(1)
         patch_ready = None
         if not rehearsal:
+            for kv in args.param:
+                planner.set_param(kv.split("=")[0], float(kv.split("=")[1]))
             planner.set_profiling(not args.no_profile)
             # HIP events on every 16th launch of a plan (~110 timed launches per run): the event packets cost ~4 us
             # each, with every 4th launch timed the episode was 3 % slower than untimed
@@ -307,6 +309,8 @@ def run_rank(args):
             planner.set_heuristic_multiplier(float(min(c.min() for c in costs)))
         planner.set_occupancy_threshold(1)
         if not rehearsal:
+            for kv in args.param:
+                planner.set_param(kv.split("=")[0], float(kv.split("=")[1]))
             planner.set_profiling(not args.no_profile)
             planner.set_param("profile_stride", 16)
             adopt_stream(planner.stream_ptr(0))
@@ -491,6 +495,8 @@ def main():
     ap.add_argument("--planner-factory", default=None, metavar="MODULE:FUNCTION",
                     help="test hook: run the episode on a CPU stand-in planner made by MODULE.FUNCTION(kind, algo, lvl, heuristic, n_maps) "
                          "(control flow of the launcher / collectives without a GPU; the line is marked as a rehearsal)")
+    ap.add_argument("--param", action="append", default=[], metavar="NAME=VALUE",
+                    help="scheduler knob for the engine (ufm_set_param / ufm_batch_set_param), e.g. owned_waves=16; for experiments -- the defaults are the product")
     ap.add_argument("--traffic-json", default="r2_traffic.json", help="file under profiles/ holding the separately collected PMC traffic of the headline run")
     args = ap.parse_args()
     if args.seed is None:

@@ -207,6 +207,46 @@ def test_resident_plan_kernel(algo, lvl):
     p.close()
 
 
+@pytest.mark.parametrize("algo,lvl", [("FD", 1), ("SG", 2), ("DFM", 1)])
+def test_resident_scheduler_variants(algo, lvl):
+    """The resident kernel's scheduler in its variants -- idle workgroups helping out or not, border values handed out during a visit
+    or only at its end, activations taken in during a visit or not (owned_flags), both wave counts, a narrow and a wide band, no tile
+    taken ahead -- only decides who visits which tile when: focused, every variant equals the oracle below the start's key; unfocused,
+    the whole FD / SG field is the same bit for bit in all of them (DFM: within its bound)."""
+    size = 520
+    cost = ufm_amd.synth.cost_map(23, size, size)
+    start, goal = ufm_amd.synth.start_goal(size, size)
+    variants = [dict(), dict(owned_flags=32), dict(owned_flags=2), dict(owned_flags=16), dict(owned_flags=34), dict(owned_flags=4), dict(owned_flags=8),
+                dict(owned_flags=1), dict(owned_waves=8), dict(owned_waves=8, owned_flags=32), dict(owned_band=1.0), dict(owned_band=1e9)]
+    o, g0 = make_pair(ALGOS[algo], lvl, cost, start, goal)
+    assert o.step() == 0
+    g0.close()
+    ref = None
+    for full in (0, 1):
+        for v in variants:
+            p = ufm_amd.Planner(ALGOS[algo], lvl)
+            p.set_param("focused", 0 if full else 1)
+            for name, val in v.items():
+                p.set_param(name, val)
+            p.set_occupancy_threshold(1); p.set_map(cost); p.set_start(*start); p.set_goal(*goal)
+            assert p.step() == 0
+            assert p.stats.resident_launches == 1 and p.stats.resident_stops == 0, v
+            assert p.check_layout() == (0, 0), v
+            if not full:
+                check_parity(o, p, "%s-%d resident %r" % (algo, lvl, v))
+            else:
+                f = p.g()
+                if ref is None:
+                    ref = f
+                elif algo != "DFM":
+                    assert np.array_equal(f, ref), v
+                else:
+                    fin = np.isfinite(ref)
+                    assert np.array_equal(fin, np.isfinite(f)), v
+                    assert np.all(np.abs(f[fin].astype(np.float64) - ref[fin]) <= DFM_RTOL * ref[fin] + 1e-30), v
+            p.close()
+
+
 def test_edge_cases():
     # tiny maps, maps smaller than a tile, non-multiple-of-tile sizes, goal in a corner, start == goal
     for (w, l) in [(1, 1), (3, 2), (33, 31), (64, 65)]:

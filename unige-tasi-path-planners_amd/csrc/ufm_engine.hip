@@ -656,7 +656,7 @@ __global__ __launch_bounds__(OWNK == 2 ? NTHR / 2 : NTHR, UFM_RELAX_WAVES) void 
     // smallest border value an early write has changed
     // (16 waves per visit only: with 8 waves and two visits per CU -- the form for jobs that are bound by the number of visits, not by
     //  their chain -- the longer visits cost more than the saved ones bring: 8192^2 plan 41.3 -> 44.0 ms)
-    constexpr bool EARLY = OWNK == 1 && UFM_EARLY_HANDOFF && !is_dfm<ALGO>;
+    constexpr bool EARLY = (OWNK == 1 || (OWNK == 2 && UFM_EARLY_HANDOFF > 1)) && UFM_EARLY_HANDOFF && !is_dfm<ALGO>;
     __shared__ float Os[EARLY ? TT : 1];
     __shared__ int s_emin[EARLY ? 16 * 9 : 1];
 #ifdef UFM_TIMING
@@ -2520,7 +2520,9 @@ int Engine::owned_phase() {
     const double limit_ms = owned_limit_ms >= 0.0f ? (double)owned_limit_ms : 200.0 + (double)P.NT / 250.0;   // (4096^2: 0.46 s; its plan takes 17 ms)
     P.own_limit = (unsigned long long)(limit_ms * 1e5);   // 100 MHz ticks
     P.own_flags = owned_flags;
-    const bool half = owned_waves == 8 || (owned_waves == 0 && (nmaps > 1 || P.NTm > 150000));
+    // (measured with the helping workgroups in place: FD 4096^2 15.9-16.3 ms with 8 waves against 16.5-16.8 with 16, 2048^2 7.25 against 6.44,
+    //  SG 2048^2 7.08 against 6.55, 1024^2 3.40 against 2.84; MS-DFM, whose visits are longer and which has no early hand-off, 2048^2 13.1 against 15.0)
+    const bool half = owned_waves == 8 || (owned_waves == 0 && (nmaps > 1 || P.NTm > (algo == UFM_ALGO_DFM ? 12000 : 50000)));
     own_layout(half ? 5 : 4);
     k_own_import<<<64, 256, 0, stream>>>(P, k);
     // 16 waves per tile visit, one visit per CU -- or 8 and two: a visit is then ~17 % longer and a CU makes 1.7 x as many.  That pays

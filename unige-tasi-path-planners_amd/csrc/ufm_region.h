@@ -18,6 +18,9 @@
 // published to the spinning host; otherwise the host carries on with the ordinary launch chain from the queues.
 // A sweep budget bounds every wave (livelock guard): what is still dirty when it runs out goes to the queues too.
 
+#ifndef UFM_REGION_IDLE_SLEEP
+#define UFM_REGION_IDLE_SLEEP 1           // an idle wave of the block kernel looks at its wake words this often (x 64 clocks)
+#endif
 constexpr int RTMAX = 10;                 // block edge in tiles
 constexpr int RN = RTMAX * T;             // ... in elements (160)
 constexpr int RP = RN + 8;                // LDS pitch of the block's field: rows 4 apart on distinct banks (168 = 5*32 + 8)
@@ -137,10 +140,20 @@ __device__ void region_phase(const DevParams &P, const RegionJob &J, float *Gs, 
     long long budget = J.max_sweeps;
     unsigned long long my_sweeps = 0;
     auto cost_at = [=](int r, int c) { const int b = Cb[r * RCP + c]; return b >= thr ? INFINITY : (float)b; };
+    // what does not change while a phase runs (thread 0 sets it between the phases): read once, not at every burst
+    const int so0 = __builtin_amdgcn_readfirstlane(S.soff[0]), so1 = __builtin_amdgcn_readfirstlane(S.soff[1]);
+    const int so2 = __builtin_amdgcn_readfirstlane(S.soff[2]), so3 = __builtin_amdgcn_readfirstlane(S.soff[3]);
+    const float Bphase = (MODE == MODE_LOWER) ? S.Bgate : INFINITY;
+    const float rb_phase = S.rbound + J.slack;
+    // words of this wave that can hold a bit at all (a block smaller than RTMAX x RTMAX leaves the upper ones empty)
+    const int nwords = min(RWW, (((nprow + 3) / 4 - 1) * RPW + (npcol + 3) / 4 + 31) / 32);
     for (;;) {
         bool took = false;
         bool vote = __hip_atomic_load(&S.giveup, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != 0;
-        for (int wd = 0; wd < RWW && !vote; ++wd) {
+        for (int wd = 0; wd < nwords && !vote; ++wd) {
+            // (looked at with a plain load first: a returning LDS atomic per word and look, most of them on empty words, was a fifth
+            //  of the time between two bursts)
+            if (__hip_atomic_load(&S.wake[w][wd], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == 0) continue;
             int bits = 0;
             if (lane == 0) bits = atomicExch(&S.wake[w][wd], 0);
             bits = __builtin_amdgcn_readfirstlane(bits);
@@ -185,14 +198,14 @@ __device__ void region_phase(const DevParams &P, const RegionJob &J, float *Gs, 
                 }
                 const int tl = (pr / TP) * J.nty + (pc / TP);
                 // the sub-round's bound (region_lower_bound); a start element itself is never held back
-                const float B = (MODE == MODE_LOWER) ? S.Bgate : INFINITY;
+                const float B = Bphase;
                 const int my_off = (lx + 1) * RP + ly + 1;
-                const bool is_start = (my_off == S.soff[0]) | (my_off == S.soff[1]) | (my_off == S.soff[2]) | (my_off == S.soff[3]);
+                const bool is_start = (my_off == so0) | (my_off == so1) | (my_off == so2) | (my_off == so3);
                 // Invalidation is held back beyond the bound per TILE, like a tile visit of k_relax: once a tile has lost a value,
                 // every unsupported value in it goes, whatever its size.  (Holding back single elements would leave unsupported
                 // values NEXT to invalidated ones: the lowering phase -- this one with its one-move slack, or the launch chain's
                 // tile visits, which do not look at single values -- would then rebuild the hole from them.)
-                const float rb = S.traised[tl] ? INFINITY : S.rbound + J.slack;
+                const float rb = (MODE == MODE_RAISE && S.traised[tl]) ? INFINITY : rb_phase;
                 asm volatile("" ::: "memory");
                 float g = ctr[0];
                 float dmin = INFINITY;                                        // smallest priority this lane deferred
@@ -244,12 +257,14 @@ __device__ void region_phase(const DevParams &P, const RegionJob &J, float *Gs, 
         if (!vote) {                                                         // nothing to do: idle until woken or all idle
             if (lane == 0) atomicAdd(&S.idle, 1);
             for (;;) {
-                __builtin_amdgcn_s_sleep(UFM_IDLE_SLEEP);
-                if (__hip_atomic_load(&S.idle, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >= 16 ||
-                    __hip_atomic_load(&S.giveup, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != 0) { vote = true; break; }
+                __builtin_amdgcn_s_sleep(UFM_REGION_IDLE_SLEEP);
+                // (all loads first, then the decisions: one LDS round trip per look)
+                const int idle_now = __hip_atomic_load(&S.idle, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                const int gave_up_now = __hip_atomic_load(&S.giveup, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 int any = 0;
 #pragma unroll
                 for (int wd = 0; wd < RWW; ++wd) any |= __hip_atomic_load(&S.wake[w][wd], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                if (idle_now >= 16 || gave_up_now != 0) { vote = true; break; }
                 if (any) { if (lane == 0) atomicSub(&S.idle, 1); break; }
             }
             if (!vote) continue;
@@ -297,7 +312,7 @@ __global__ __launch_bounds__(NTHR) void k_replan_region(DevParams P, RegionJobs 
     __syncthreads();
     for (int i = tid; i < 2 * RTMAX * RTMAX; i += NTHR) (&S.dprio[0][0])[i] = INFBITS;
     for (int i = tid; i < RFRAME; i += NTHR) { S.actL[i] = INFBITS; S.actR[i] = INFBITS; }
-    if (tid == 0) S.rmin = INFBITS;
+    if (tid == 0) { S.rmin = INFBITS; S.m_r = INFBITS; }
     const float hm = J.dyn.hm;
     const int thr = J.dyn.thr, focused = J.dyn.focused;
     {   // pending seeds of this map (all consumed): tiles inside the block are handled here, any other goes to the queue
@@ -377,13 +392,8 @@ __global__ __launch_bounds__(NTHR) void k_replan_region(DevParams P, RegionJobs 
     for (int round = 0;; ++round) {
         for (;;) {
             region_phase<ALGO, MODE_RAISE>(P, J, Gs, Cb, S, thr, hm, focused, goal_lx, goal_ly);
-            if (tid == 0) {        // a tile that lost a value after some of its patches had been held back: those patches again
-                int again = 0;
-                for (int i = 0; i < ntl; ++i) again |= (S.traised[i] && S.dprio[1][i] != INFBITS) ? 1 : 0;
-                S.again = (again && !S.giveup) ? 1 : 0;
-            }
-            __syncthreads();
-            const int again_t = S.again;
+            // a tile that lost a value after some of its patches had been held back: those patches again
+            const int again_t = __syncthreads_or(tid < ntl && S.traised[tid] && S.dprio[1][tid] != INFBITS) && !S.giveup;
             __syncthreads();
             if (!again_t) break;
             for (int i = tid; i < 16 * RWW; i += NTHR) { (&S.wake[0][0])[i] |= (&S.defer[1][0][0])[i]; (&S.defer[1][0][0])[i] = 0; }
@@ -429,10 +439,12 @@ __global__ __launch_bounds__(NTHR) void k_replan_region(DevParams P, RegionJobs 
             if (tid == 0) S.dkey = INFBITS;
             __syncthreads();
         }
+        if (tid < ntl && S.dprio[1][tid] != INFBITS) atomicMin(&S.m_r, S.dprio[1][tid]);     // (S.m_r: INFBITS here, reset below)
+        __syncthreads();
         if (tid == 0) {
             const float B = focused ? region_lower_bound(Gs, S) : INFINITY;
-            int m = INFBITS;
-            for (int i = 0; i < ntl; ++i) m = min(m, S.dprio[1][i]);
+            const int m = S.m_r;
+            S.m_r = INFBITS;
             bool again = !S.giveup && focused && m != INFBITS && __int_as_float(m) < B + J.slack;   // lowering reaches the key plus one move
             if (again && round >= 14) { again = false; S.giveup = 1; }
             if (again) S.rbound = fmaxf(B, S.rbound) + J.rb.band;
@@ -460,18 +472,27 @@ __global__ __launch_bounds__(NTHR) void k_replan_region(DevParams P, RegionJobs 
     constexpr int PER = (RTMAX * RTMAX * TT + NTHR - 1) / NTHR;      // elements per thread (25)
     float init[PER];
     int n_exp = 0;
+    // (the values HBM holds, for all of this thread's elements at once: asked for one after the other, each in front of its
+    //  comparison, they were nine memory round trips in a row)
 #pragma unroll
     for (int it = 0; it < PER; ++it) {
         const int i = tid + it * NTHR;
         init[it] = 0.0f;
+        if (i < ntl * TT && S.tflag[i / TT]) {
+            const int tl = i / TT, ti = tl / J.nty, tj = tl - ti * J.nty;
+            init[it] = P.G[(size_t)(gt0 + (J.tx0 + ti) * P.TY + J.ty0 + tj) * TT + (i - tl * TT)];
+        }
+    }
+#pragma unroll
+    for (int it = 0; it < PER; ++it) {
+        const int i = tid + it * NTHR;
         if (i >= ntl * TT) continue;
         const int tl = i / TT, e = i - tl * TT, ti = tl / J.nty, tj = tl - ti * J.nty;
         if (!S.tflag[tl]) continue;                                         // nothing was applied in this tile
         const int tx = J.tx0 + ti, ty = J.ty0 + tj, gt = gt0 + tx * P.TY + ty;
         const int io_r = e / T, io_c = e % T;
-        const float gl0 = P.G[(size_t)gt * TT + e];
+        const float gl0 = init[it];
         const float gf = Gs[(ti * T + io_r + 1) * RP + tj * T + io_c + 1];
-        init[it] = gl0;
         if (gf == gl0) continue;
         ++n_exp;
         P.G[(size_t)gt * TT + e] = gf;
@@ -553,12 +574,15 @@ __global__ __launch_bounds__(NTHR) void k_replan_region(DevParams P, RegionJobs 
     {
         const float B = focused ? region_start_key(Gs, S) : INFINITY;
         int mr = INFBITS, ml = INFBITS;
+        // (the four list lengths together, before the first list is walked)
         const int nr = __hip_atomic_load(&P.ctr->cnt[Q_RAISE][J.rb.k_raise % 3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int npr = __hip_atomic_load(&P.ctr->npark[Q_RAISE], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int nl = __hip_atomic_load(&P.ctr->cnt[Q_LOWER][J.k_lower % 3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int npl = __hip_atomic_load(&P.ctr->npark[Q_LOWER], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         for (int i = tid; i < nr; i += NTHR) {
             const int gt = __hip_atomic_load(&P.cand[(size_t)(Q_RAISE * 3 + J.rb.k_raise % 3) * P.NT + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (gt / P.NTm == m) mr = min(mr, prio_read_fresh(P, Q_RAISE, J.rb.k_raise, gt));
         }
-        const int npr = __hip_atomic_load(&P.ctr->npark[Q_RAISE], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         for (int i = tid; i < npr; i += NTHR) {
             const int gt = __hip_atomic_load(&P.park[(size_t)(Q_RAISE * 2) * P.NT + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (gt / P.NTm == m) mr = min(mr, __hip_atomic_load(&P.pprio[Q_RAISE * P.NT + gt], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
@@ -568,12 +592,10 @@ __global__ __launch_bounds__(NTHR) void k_replan_region(DevParams P, RegionJobs 
             return __int_as_float(pbits) + (focused ? tile_heuristic(P, m, (gt - gt0) / P.TY, (gt - gt0) % P.TY) : 0.0f);
         };
         float kl = INFINITY;
-        const int nl = __hip_atomic_load(&P.ctr->cnt[Q_LOWER][J.k_lower % 3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         for (int i = tid; i < nl; i += NTHR) {
             const int gt = __hip_atomic_load(&P.cand[(size_t)(Q_LOWER * 3 + J.k_lower % 3) * P.NT + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             kl = fminf(kl, lower_key(gt, prio_read_fresh(P, Q_LOWER, J.k_lower, gt)));
         }
-        const int npl = __hip_atomic_load(&P.ctr->npark[Q_LOWER], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         for (int i = tid; i < npl; i += NTHR) {
             const int gt = __hip_atomic_load(&P.park[(size_t)(Q_LOWER * 2) * P.NT + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             kl = fminf(kl, lower_key(gt, __hip_atomic_load(&P.pprio[Q_LOWER * P.NT + gt], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)));
