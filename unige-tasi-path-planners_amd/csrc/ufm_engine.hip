@@ -98,6 +98,12 @@ constexpr int NTHR = 1024;     // 16 waves; four lanes per node, each wave owns 
 #ifndef UFM_EARLY_HANDOFF
 #define UFM_EARLY_HANDOFF 1    // resident kernel, FD / SG: a border patch that has gone quiet writes its lowered border values out and
 #endif                         // queues the neighbours at once, while the rest of the tile is still being swept (k_relax)
+#ifndef UFM_LOOK_SLEEP
+#define UFM_LOOK_SLEEP 32      // pause of a workgroup that found nothing to visit before it looks again (x 64 clocks)
+#endif
+#ifndef UFM_STEAL_VICTIMS
+#define UFM_STEAL_VICTIMS 4    // owners whose words an idle workgroup looks at per look (k_relax, own_steal)
+#endif
 #ifndef UFM_EARLY_POLLS
 #define UFM_EARLY_POLLS 6      // ... its queue words follow after this many looks of the idle wave at its wake bits (the stores have landed by then)
 #endif
@@ -830,14 +836,19 @@ __global__ __launch_bounds__(OWNK == 2 ? NTHR / 2 : NTHR, UFM_RELAX_WAVES) void 
         // (whose words: not the holder of the smallest priority -- its best tile is as a rule the one it is visiting, and every idle
         //  workgroup would go for the same word -- but a different owner at every look; the smallest hint is the floor of the band)
         ++steal_seq;
-        const int vo = ((int)blockIdx.x + 1 + (int)((unsigned int)(steal_seq * 61 + (int)blockIdx.x * 17) % (unsigned int)(P.own_nw - 1))) % P.own_nw;
-        const int *vq = P.own_prio + (size_t)vo * P.own_slots;
-        unsigned long long bb = ~0ull;
+        unsigned long long bb = ~0ull;         // {priority, which of the owners looked at, slot}
+        int vos[UFM_STEAL_VICTIMS];
+#pragma unroll
+        for (int vi = 0; vi < UFM_STEAL_VICTIMS; ++vi) {
+            const int vo = ((int)blockIdx.x + 1 + (int)((unsigned int)((steal_seq * UFM_STEAL_VICTIMS + vi) * 61 + (int)blockIdx.x * 17) % (unsigned int)(P.own_nw - 1))) % P.own_nw;
+            vos[vi] = vo;
+            const int *vq = P.own_prio + (size_t)vo * P.own_slots;
 #pragma unroll 1
-        for (int sl = tid; sl < P.own_slots; sl += NTH) {
-            const int v = __hip_atomic_load(&vq[sl], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const int lk = __hip_atomic_load(&P.own_lock[(size_t)vo * P.own_slots + sl], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (v < INFBITS && lk == 0) bb = min(bb, ((unsigned long long)(unsigned int)v << 32) | (unsigned int)sl);
+            for (int sl = tid; sl < P.own_slots; sl += NTH) {
+                const int v = __hip_atomic_load(&vq[sl], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const int lk = __hip_atomic_load(&P.own_lock[(size_t)vo * P.own_slots + sl], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (v < INFBITS && lk == 0) bb = min(bb, ((unsigned long long)(unsigned int)v << 32) | ((unsigned int)vi << 28) | (unsigned int)sl);
+            }
         }
         for (int o_ = 32; o_; o_ >>= 1) bb = min(bb, (unsigned long long)__shfl_xor((long long)bb, o_));
         if (tid == 0) s_best = ~0ull;
@@ -851,7 +862,10 @@ __global__ __launch_bounds__(OWNK == 2 ? NTHR / 2 : NTHR, UFM_RELAX_WAVES) void 
             if (b2 != ~0ull && !(__int_as_float((int)(b2 >> 32)) > __int_as_float((int)(vk >> 32)) + delta)) atomicAdd(&g_sdiag[4], 1ull);
 #endif
             if (b2 != ~0ull && !(__int_as_float((int)(b2 >> 32)) > __int_as_float((int)(vk >> 32)) + delta)) {
-                const int gw = vo * P.own_slots + (int)(unsigned int)b2;
+                int vo = vos[0];
+#pragma unroll
+                for (int vi = 1; vi < UFM_STEAL_VICTIMS; ++vi) if ((int)(((unsigned int)b2 >> 28) & 15u) == vi) vo = vos[vi];
+                const int gw = vo * P.own_slots + (int)((unsigned int)b2 & 0x0FFFFFFFu);
                 int pr = (int)(b2 >> 32);
                 int r_old, r_lk;
                 own_take_issue(gw, pr, r_old, r_lk);
@@ -940,7 +954,7 @@ __global__ __launch_bounds__(OWNK == 2 ? NTHR / 2 : NTHR, UFM_RELAX_WAVES) void 
                     int got = -1;
                     if ((votes & 1) && !(P.own_flags & 32)) got = own_steal(hint);
                     if (got >= 0) own_next = __builtin_amdgcn_readfirstlane(got);
-                    else __builtin_amdgcn_s_sleep(32);
+                    else __builtin_amdgcn_s_sleep(UFM_LOOK_SLEEP);
                 }
             }
             if (own_next < 0) break;
