@@ -37,9 +37,11 @@ def kernel(name):
             "traffic_bytes_per_launch": 1024.0 * (corr_r * f + corr_w * w),
             "rocprof_avg_launch_us": avg_us, "rocprof_calls": calls}
 
-main = kernel("k_relax<0, 0, false, 1>")
+form = 2 if "k_relax<0, 0, false, 2>" in stats else 1      # 8 waves per tile visit and 512 workgroups, or 16 and 256
+main = kernel("k_relax<0, 0, false, %d>" % form)
 out = {
-    "kernel": "k_relax<FD,LOWER,resident> = k_relax<0, 0, false, 1> in %s_kernel_stats.csv (16 waves per tile visit, 256 workgroups): the resident lowering kernel, one launch per plan (the whole lowering phase); the launch bench.py brackets with HIP events" % tag,
+    "kernel": "k_relax<FD,LOWER,resident> = k_relax<0, 0, false, %d> in %s_kernel_stats.csv (%s): the resident lowering kernel, one launch per plan (the whole lowering phase); the launch bench.py brackets with HIP events" % (
+        form, tag, "8 waves per tile visit, 512 workgroups" if form == 2 else "16 waves per tile visit, 256 workgroups"),
     "fetch_correction": corr_r, "write_correction": corr_w,
     "calibration": "tools/traffic_calib.hip: 1 GiB dword stream -> FETCH_SIZE %.0f KB, WRITE_SIZE %.0f KB" % (cal_r, cal_w),
     "command": "python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline (rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes; tools/collect_profiles.sh)",

@@ -98,6 +98,9 @@ constexpr int NTHR = 1024;     // 16 waves; four lanes per node, each wave owns 
 #ifndef UFM_EARLY_HANDOFF
 #define UFM_EARLY_HANDOFF 1    // resident kernel, FD / SG: a border patch that has gone quiet writes its lowered border values out and
 #endif                         // queues the neighbours at once, while the rest of the tile is still being swept (k_relax)
+#ifndef UFM_HINT_SAMPLE
+#define UFM_HINT_SAMPLE 64     // hints (other owners' smallest priorities) a visit loads ahead for the choice of the next tile
+#endif
 #ifndef UFM_LOOK_SLEEP
 #define UFM_LOOK_SLEEP 32      // pause of a workgroup that found nothing to visit before it looks again (x 64 clocks)
 #endif
@@ -738,6 +741,7 @@ __global__ __launch_bounds__(OWNK == 2 ? NTHR / 2 : NTHR, UFM_RELAX_WAVES) void 
     int *const own_q = OWN ? P.own_prio + (size_t)blockIdx.x * P.own_slots : nullptr;
     const int own_base = OWN ? (int)blockIdx.x * P.own_slots : 0;
     int own_next = -1, own_slot_now = -1;   // (the same in every thread)
+    int own_hrot = 0;                       // which part of the hints the visit in progress has loaded ahead
     const unsigned long long own_t0 = OWN ? wall_clock64() : 0ull;
     if (OWN && tid == 0) { s_own[0] = -1; s_own[1] = -1; s_own[2] = 0; s_late = 0; }
     if constexpr (OWN) {   // the start elements of the first 64 maps: address in G and the heuristic term of their keys (start_bound())
@@ -898,8 +902,10 @@ __global__ __launch_bounds__(OWNK == 2 ? NTHR / 2 : NTHR, UFM_RELAX_WAVES) void 
                 const bool have = b != ~0ull;
                 const bool take = have && !(votes & 2);        // inside the ordering band
                 bool stop = false;
-                if (!have && !(votes & 1)) {
-                    // nobody seems to hold anything: two collects of all queue words; identical and all empty = the phase is over
+                if (!have && !(votes & 1) && blockIdx.x == 0) {
+                    // nobody seems to hold anything: two collects of all queue words; identical and all empty = the phase is over.
+                    // (Workgroup 0 alone looks -- it tells the others through own_abort = 2: with every workgroup collecting for itself the
+                    //  end of a 4096^2 plan was 512 x 2 x 264 KB of loads.)
                     unsigned long long h0 = 0ull, h1 = 1ull;
                     bool ok = true;
                     const int total = P.own_nw * P.own_slots;
@@ -926,6 +932,8 @@ __global__ __launch_bounds__(OWNK == 2 ? NTHR / 2 : NTHR, UFM_RELAX_WAVES) void 
                     int flag = 0;
                     // hand back to the launch chain (k_own_export): never stay for ever -- and not alone: a workgroup that only became
                     // resident when the others had left (the device was shared) must not wait out a limit of its own
+                    if (aborted == 2) stop = true;            // workgroup 0 has seen the end
+                    else if (stop) __hip_atomic_store(&P.ctr->own_abort, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     const bool late = !stop && (aborted || wall_clock64() - own_t0 > P.own_limit || s_own[2] > 16000);
                     if (late) { atomicAdd(&P.ctr->own_stops, 1); __hip_atomic_store(&P.ctr->own_abort, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
                     const bool taking = take && !stop && !late;
@@ -1210,7 +1218,13 @@ __global__ __launch_bounds__(OWNK == 2 ? NTHR / 2 : NTHR, UFM_RELAX_WAVES) void 
             typedef __attribute__((address_space(3))) void *lds_ptr;
             typedef const __attribute__((address_space(1))) void *glb_ptr;
             __builtin_amdgcn_global_load_lds((glb_ptr)(own_q + min(tid, P.own_slots - 1)), (lds_ptr)(s_pf + (tid & ~63)), 4, 0, 16);              // (16: sc1)
-            if (tid < P.own_nw) __builtin_amdgcn_global_load_lds((glb_ptr)(P.own_min + tid), (lds_ptr)(s_pfh + (tid & ~63)), 4, 0, 16);
+            // (the hints: a different quarter or half of them at every visit -- the band is a heuristic, 2 KB of hints per visit next to
+            //  1.8 KB of tile data is not)
+            ++own_hrot;
+            if (tid < UFM_HINT_SAMPLE) {
+                const int ho = (tid + own_hrot * UFM_HINT_SAMPLE) % P.own_nw;
+                __builtin_amdgcn_global_load_lds((glb_ptr)(P.own_min + ho), (lds_ptr)(s_pfh + (tid & ~63)), 4, 0, 16);
+            }
         }
 
         // per-lane constants of the wave's four patches
@@ -1475,7 +1489,7 @@ __global__ __launch_bounds__(OWNK == 2 ? NTHR / 2 : NTHR, UFM_RELAX_WAVES) void 
             // The next tile is chosen and marked now, from the queue words as they were when this visit began to sweep: the
             // exchange is on its way while this visit is written back, and the next visit's loads follow the write-back with no
             // queue round trip in between.  (A fresh look costs two round trips in a row -- words, then exchange -- per visit.)
-            own_decide(tid < P.own_slots ? s_pf[tid] : INFBITS, (tid < P.own_nw && tid != (int)blockIdx.x) ? s_pfh[tid] : INFBITS,
+            own_decide(tid < P.own_slots ? s_pf[tid] : INFBITS, (tid < UFM_HINT_SAMPLE && (tid + own_hrot * UFM_HINT_SAMPLE) % P.own_nw != (int)blockIdx.x) ? s_pfh[tid] : INFBITS,
                        (own_slot_now >= own_base && own_slot_now < own_base + P.own_slots) ? own_slot_now - own_base : -1);
             const unsigned long long b = s_best;
             const bool take = b != ~0ull && !(s_gmin & 2) && !(P.own_flags & 1) && !s_late;
