@@ -123,7 +123,9 @@ int ufm_check_layout(ufm_t *p, uint64_t *bad_ring_entries, uint64_t *bad_cost_by
  * "owned" (default 1): a step that (re)initialises a search runs its lowering phase as ONE resident launch -- 256
  * workgroups, each serving the tiles it owns from one queue word per tile -- instead of a launch per ordering band
  * ("owned_band": its band in tile crossings; "owned_limit_ms": it hands back to the launch chain after this long,
- * default: by the size of the job (0.2 s + 4 us per tile); "owned_waves": 16 waves per tile visit and 256 workgroups, 8 and 512, or 0 = by the size of the job);
+ * default: by the size of the job (0.2 s + 4 us per tile); "owned_waves": 16 waves per tile visit and 256 workgroups, 8 and 512, or 0 = by the size of the job;
+ * "owned_flags": variants of its scheduler for measurements -- 32: idle workgroups do not visit other owners' tiles, 2: no hand-off of border values during a
+ * visit, 16: no activations taken in during a visit -- which change who visits which tile when, never a result);
  * 0: launch chain only.  ufm_stats::resident_* report it. ---- */
 int ufm_set_param(ufm_t *p, const char *name, double value);
 
