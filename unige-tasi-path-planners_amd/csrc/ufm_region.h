@@ -143,6 +143,9 @@ __device__ void region_phase(const DevParams &P, const RegionJob &J, float *Gs, 
     // what does not change while a phase runs (thread 0 sets it between the phases): read once, not at every burst
     const int so0 = __builtin_amdgcn_readfirstlane(S.soff[0]), so1 = __builtin_amdgcn_readfirstlane(S.soff[1]);
     const int so2 = __builtin_amdgcn_readfirstlane(S.soff[2]), so3 = __builtin_amdgcn_readfirstlane(S.soff[3]);
+    // (J lives in the kernel's argument segment: a field of it read inside the sweep loop is a scalar memory load, waited for, in
+    //  every sweep -- J.debug was)
+    const bool dbg_nogate = (J.debug & 1) != 0, dbg_count = (J.debug & 2) != 0;
     const float Bphase = (MODE == MODE_LOWER) ? S.Bgate : INFINITY;
     const float rb_phase = S.rbound + J.slack;
     // words of this wave that can hold a bit at all (a block smaller than RTMAX x RTMAX leaves the upper ones empty)
@@ -209,6 +212,7 @@ __device__ void region_phase(const DevParams &P, const RegionJob &J, float *Gs, 
                 asm volatile("" ::: "memory");
                 float g = ctr[0];
                 float dmin = INFINITY;                                        // smallest priority this lane deferred
+                float rmin_l = INFINITY;                                      // smallest value this lane invalidated
                 bool again = true;
                 int cnt = 0;
                 for (int b = 0; b < 16 && again; ++b) {
@@ -218,16 +222,16 @@ __device__ void region_phase(const DevParams &P, const RegionJob &J, float *Gs, 
                     bool want, gate, doit;
                     if (MODE == MODE_LOWER) {
                         want = (nv != g);
-                        gate = (nv + hd < B) | (B == INFINITY) | is_start | ((J.debug & 1) != 0);    // end_condition: results at / beyond the start's key wait
+                        gate = (nv + hd < B) | (B == INFINITY) | is_start | dbg_nogate;    // end_condition: results at / beyond the start's key wait
                         doit = want & gate & ((nv < g) | (colour == (cnt & 3)));
                         if (want & !gate) dmin = fminf(dmin, nv);
                     } else {
                         if (is_dfm<ALGO>) want = (g < INFINITY) & (nv > g) & ((nv == INFINITY) | (__float_as_int(nv) - __float_as_int(g) > 8));
                         else want = (g < INFINITY) & (nv > g);
-                        gate = !(g > rb) | ((J.debug & 1) != 0);                                     // beyond the invalidation bound: wait
+                        gate = !(g > rb) | dbg_nogate;                                               // beyond the invalidation bound: wait
                         doit = want & gate;
                         if (want & !gate) dmin = fminf(dmin, g);
-                        if (doit & (q == 0)) { atomicMin(&S.rmin, __float_as_int(g)); S.traised[tl] = 1; }
+                        rmin_l = doit ? fminf(rmin_l, g) : rmin_l;        // (what the burst took away: into S.rmin / S.traised after it, not per sweep)
                         nv = INFINITY;
                     }
                     if (doit && q == 0) ctr[0] = nv;
@@ -243,7 +247,8 @@ __device__ void region_phase(const DevParams &P, const RegionJob &J, float *Gs, 
                     again = wanted != 0ull;
                 }
                 budget -= cnt; my_sweeps += cnt;
-                if ((J.debug & 2) && lane == 0) { atomicAdd(&S.dbg[MODE == MODE_LOWER ? 5 : 4], 1); atomicAdd(&S.dbg[MODE == MODE_LOWER ? 7 : 6], cnt); }
+                if (MODE == MODE_RAISE && rmin_l < INFINITY && q == 0) { atomicMin(&S.rmin, __float_as_int(rmin_l)); S.traised[tl] = 1; }
+                if (dbg_count && lane == 0) { atomicAdd(&S.dbg[MODE == MODE_LOWER ? 5 : 4], 1); atomicAdd(&S.dbg[MODE == MODE_LOWER ? 7 : 6], cnt); }
                 if (again && lane == 0) __hip_atomic_fetch_or(&S.wake[w][wd], 1 << j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // burst cap
                 if (dmin < INFINITY && q == 0) {
                     atomicAdd(&S.dbg[MODE == MODE_LOWER ? 0 : 1], 1);
