@@ -2817,6 +2817,7 @@ int Engine::step(ufm_stats *out) {
     uint64_t updated = 0;
     bool have_seeds = false;
     bool fast_done = false;
+    bool skip_raise = false;      // the block kernel has left nothing to invalidate below its bound (only lowering work beyond the block)
     // margin of the invalidation bound above the start's current key (the key may rise through the patch)
     const float band = raise_margin * (delta_abs >= 0.0f ? delta_abs : delta_scale * T * mean_cost);
     if (n_upd > 0 || n_init > 0) {
@@ -2924,6 +2925,13 @@ int Engine::step(ufm_stats *out) {
             if (rc != UFM_OK) return rc;
             region_runs += (uint32_t)rjs.n;
             if (h_ctr->done) region_done += (uint32_t)rjs.n;
+            else if (!rjs.j[0].batch && focused) {
+                // (its end check has the smallest invalidation priority of this map, queued or parked: at or beyond the bound means the
+                //  launch chain's invalidation phase -- two batches of launches and two host round trips -- would release nothing)
+                float qm;
+                std::memcpy(&qm, &h_ctr->qmin[Q_RAISE], sizeof(float));
+                skip_raise = !(qm < h_ctr->rbound);
+            }
         } else if (graphed) {
             rb.k_raise = iter[Q_RAISE]; rb.band = band;
             hipGraphExec_t ge = nullptr;
@@ -3054,7 +3062,7 @@ int Engine::step(ufm_stats *out) {
         }
         for (int round = 0; round < 64; ++round) {
             const auto ta = std::chrono::steady_clock::now();
-            if (do_raise) {
+            if (do_raise && !(skip_raise && round == 0)) {
                 uint32_t rl = 0;
                 float rk = 0.0f;
                 k_unpark<<<1, 1024, 0, stream>>>(P, Q_RAISE, iter[Q_RAISE], rbound);
