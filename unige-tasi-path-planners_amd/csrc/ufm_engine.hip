@@ -2911,8 +2911,10 @@ int Engine::step(ufm_stats *out) {
         if (regioned) {
             const unsigned int seq = ++pub_seq;
             for (int i = 0; i < rjs.n; ++i) rjs.j[i].seq = seq;
-            if (rjs.j[0].batch)     // the counters the maps' workgroups add to
+            if (rjs.j[0].batch) {   // the counters the maps' workgroups add to
                 HIPCHK(hipMemsetAsync(&P.ctr->rbound, 0, offsetof(DevCounters, done_fail) + sizeof(int) - offsetof(DevCounters, rbound), stream));
+                k_fill<<<1, 64, 0, stream>>>(reinterpret_cast<float *>(&P.ctr->qmin[Q_RAISE]), (size_t)1, INFINITY);
+            }
             dyn_dev = dyn_now; dyn_pending = false;
             const dim3 g(rjs.n), b(NTHR);
             if (algo == UFM_ALGO_FD) k_replan_region<UFM_ALGO_FD><<<g, b, 0, stream>>>(P, rjs, h_ctr, h_flag);
@@ -2925,9 +2927,10 @@ int Engine::step(ufm_stats *out) {
             if (rc != UFM_OK) return rc;
             region_runs += (uint32_t)rjs.n;
             if (h_ctr->done) region_done += (uint32_t)rjs.n;
-            else if (!rjs.j[0].batch && focused) {
-                // (its end check has the smallest invalidation priority of this map, queued or parked: at or beyond the bound means the
-                //  launch chain's invalidation phase -- two batches of launches and two host round trips -- would release nothing)
+            else if (focused) {
+                // (its end check has the smallest invalidation priority of the map -- of any map of a batch --, queued or parked: at or
+                //  beyond the bound -- a batch: the largest of the maps' bounds -- means the launch chain's invalidation phase, two batches
+                //  of launches and two host round trips, would release nothing)
                 float qm;
                 std::memcpy(&qm, &h_ctr->qmin[Q_RAISE], sizeof(float));
                 skip_raise = !(qm < h_ctr->rbound);

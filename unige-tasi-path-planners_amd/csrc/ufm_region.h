@@ -632,6 +632,8 @@ __global__ __launch_bounds__(NTHR) void k_replan_region(DevParams P, RegionJobs 
                 if (done) P.ctr->expanded = (unsigned long long)S.expanded;
             } else {           // shared counters (the host zeroed them for the step); the last workgroup draws the conclusion
                 if (!done) atomicAdd(&P.ctr->done_fail, 1);
+                // (does any map of the round have an invalidation left below ITS bound?  0 = yes: the host compares with the round's bound)
+                if (S.m_r != INFBITS && __int_as_float(S.m_r) < S.rbound) atomicMin(&P.ctr->qmin[Q_RAISE], 0);
                 atomicMax(reinterpret_cast<int *>(&P.ctr->rbound), __float_as_int(S.rbound));   // (positive floats order like their bits)
                 atomicAdd(&P.ctr->updated, upd);
                 atomicAdd(&P.ctr->tile_visits, (unsigned long long)ntl);
