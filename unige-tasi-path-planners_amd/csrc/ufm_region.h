@@ -19,7 +19,7 @@
 // A sweep budget bounds every wave (livelock guard): what is still dirty when it runs out goes to the queues too.
 
 #ifndef UFM_REGION_IDLE_SLEEP
-#define UFM_REGION_IDLE_SLEEP 1           // an idle wave of the block kernel looks at its wake words this often (x 64 clocks)
+#define UFM_REGION_IDLE_SLEEP 16          // an idle wave of the block kernel looks at its wake words this often (x 64 clocks): 1 / 4 / 16 / 32 / 64 -> 100 replans 18.9 / 18.0 / 17.6 / 17.6 / 17.8 ms (the looks of twelve idle waves take issue slots and LDS cycles from the four that sweep)
 #endif
 constexpr int RTMAX = 10;                 // block edge in tiles
 constexpr int RN = RTMAX * T;             // ... in elements (160)
