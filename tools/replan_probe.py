@@ -7,6 +7,8 @@ import numpy as np, ufm_amd, torch
 size = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 algo = sys.argv[2] if len(sys.argv) > 2 else "FD"
 params = dict(kv.split("=") for kv in sys.argv[3:])
+if "lib" in params:
+    ufm_amd.use_library(os.path.join(ROOT, params.pop("lib")))
 A = {"FD": ufm_amd.ALGO_FD, "SG": ufm_amd.ALGO_SG, "DFM": ufm_amd.ALGO_DFM}[algo]
 seed = 7
 cost = ufm_amd.synth.cost_map(seed, size, size)

@@ -8,10 +8,13 @@ size, seed = 4096, 7
 cost = ufm_amd.synth.cost_map(seed, size, size)
 start, goal = ufm_amd.synth.start_goal(size, size)
 script = list(ufm_amd.synth.replan_script(seed, size, size, n_patches=12))
+args = dict(kv.split("=") for kv in sys.argv[1:])
+if "lib" in args:
+    ufm_amd.use_library(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), args.pop("lib")))
 p = ufm_amd.Planner(ufm_amd.ALGO_FD, 1)
 p.set_param("region_debug", 2)
-for kv in sys.argv[1:]:
-    k, v = kv.split("="); p.set_param(k, float(v))
+for k, v in args.items():
+    p.set_param(k, float(v))
 p.set_occupancy_threshold(1); p.set_map(cost); p.set_start(*start); p.set_goal(*goal)
 assert p.step() == 0
 for i, (k, s, top, left, patch) in enumerate(script):

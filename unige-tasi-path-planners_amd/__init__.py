@@ -9,7 +9,7 @@ without the HIP library / a GPU raises.
 """
 from .capi import (  # noqa: F401
     ALGO_FD, ALGO_SG, ALGO_DFM, LOOP_OK, LOOP_FAILURE_NO_GRAPH, LOOP_FAILURE_NO_GOAL,
-    UfmError, Planner, BatchPlanner, Stats, PathInfo, load_library, library_path, build_library,
+    UfmError, Planner, BatchPlanner, Stats, PathInfo, load_library, library_path, build_library, use_library,
 )
 from . import capi  # noqa: F401
 from . import synth  # noqa: F401

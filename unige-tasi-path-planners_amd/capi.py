@@ -67,9 +67,20 @@ class PathInfo(C.Structure):
     ]
 
 
+_LIB_PATH = os.path.join(_HERE, "libufm.so")
+
+
 def library_path():
-    # UFM_LIB: alternative build of the same library (kernel tuning experiments)
-    return os.environ.get("UFM_LIB") or os.path.join(_HERE, "libufm.so")
+    return _LIB_PATH
+
+
+def use_library(path):
+    """Bind another build of the same library (tools/: kernel tuning experiments, diagnostic builds).  Explicit, per
+    process, before the first planner is created -- the product, the tests and bench.py never call this."""
+    global _LIB_PATH
+    if _LIB is not None:
+        raise UfmError("use_library() after the library has been loaded")
+    _LIB_PATH = os.path.abspath(path)
 
 
 def build_library():

@@ -405,6 +405,11 @@ __device__ __forceinline__ void trace_rec(int k, int kind, unsigned long long t0
 #define UFM_WREC(type, val)
 #endif
 
+#ifdef UFM_SWEEPSTAT
+// diagnostics (-DUFM_SWEEPSTAT, tools/sweep_stats.py): what the patch sweeps of k_relax find.  [0] sweeps, [1] sweeps that changed no node,
+// [2] node values changed, [3] bursts, [4] bursts whose first sweep changed nothing, [5] node values lowered, [8..23] histogram of sweeps per burst (1..16)
+__device__ unsigned long long g_sstat[32];
+#endif
 // ---- update operators -------------------------------------------------------
 // Correctly rounded fp32 square root (std::sqrt of the reference, Macros.h:12):
 // v_sqrt_f32 is good to 1 ulp; two fused residuals pick the neighbour that is
@@ -1363,6 +1368,9 @@ __global__ __launch_bounds__(OWNK == 2 ? NTHR / 2 : NTHR, UFM_RELAX_WAVES) void 
                     // re-reading it from LDS after the evaluation only put a second LDS round trip on the
                     // dependent chain of every sweep
                     float g = ctr[0];
+#ifdef UFM_SWEEPSTAT
+                    const int sst_c0 = cnt[j];
+#endif
                     for (int b = 0; b < 16 && again; ++b) {
                         asm volatile("" ::: "memory");   // re-read the LDS tile every sweep (other waves and lanes write it)
                         float nv = quad_min(eval_quad<ALGO>(ctr, q, C[j]));
@@ -1393,6 +1401,18 @@ __global__ __launch_bounds__(OWNK == 2 ? NTHR / 2 : NTHR, UFM_RELAX_WAVES) void 
                         if (MODE == MODE_RAISE) wanted = mask;
                         else if (is_dfm<ALGO>) wanted = __builtin_amdgcn_ballot_w64(want);
                         else wanted = __builtin_amdgcn_fcmpf(nv, g, 14);   // lanes with nv != g (14 = FCMP_UNE), as a v_cmp into an SGPR pair
+#ifdef UFM_SWEEPSTAT
+                        {
+                            const unsigned long long chg = __builtin_amdgcn_ballot_w64(gn != g), low = __builtin_amdgcn_ballot_w64(gn < g);
+                            if (lane == 0) {
+                                atomicAdd(&g_sstat[0], 1ull);
+                                if (!chg) atomicAdd(&g_sstat[1], 1ull);
+                                atomicAdd(&g_sstat[2], (unsigned long long)__popcll(chg) / 4ull);
+                                atomicAdd(&g_sstat[5], (unsigned long long)__popcll(low) / 4ull);
+                                if (b == 0) { atomicAdd(&g_sstat[3], 1ull); if (!chg) atomicAdd(&g_sstat[4], 1ull); }
+                            }
+                        }
+#endif
                         g = gn;
                         UFM_SWEEP_FENCE();                               // value before wake bit
                         if ((mask & wake_sel) != 0ull && wbit[j] && lane != 4)
@@ -1401,6 +1421,9 @@ __global__ __launch_bounds__(OWNK == 2 ? NTHR / 2 : NTHR, UFM_RELAX_WAVES) void 
                         ++tot;
                         again = wanted != 0ull;
                     }
+#ifdef UFM_SWEEPSTAT
+                    if (lane == 0) atomicAdd(&g_sstat[8 + min(cnt[j] - sst_c0, 16) - 1], 1ull);
+#endif
                     if (again && lane == 0)              // burst cap: leave the rest to the next take
                         __hip_atomic_fetch_or(&s_wake[w], 1 << j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                     if constexpr (EARLY) if (!(P.own_flags & 2)) {
@@ -1454,7 +1477,8 @@ __global__ __launch_bounds__(OWNK == 2 ? NTHR / 2 : NTHR, UFM_RELAX_WAVES) void 
                         if (ew_pend && polls >= UFM_EARLY_POLLS) ew_flush();   // (the stores are ~1 us old by now: no wait)
                         // (not in a visit that ended at the end condition: an activation taken back there -- its priority may lie below
                         //  the start's key -- would be lost with the sweeps that visit does not make)
-                        if (!(P.own_flags & 18) && !(__hip_atomic_load(&s_qw[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) & 0x20000)) {
+                        // (the refresh reloads the 68 floats of a 16 x 16 tile's ring record with one wave)
+                        if (T == 16 && !(P.own_flags & 18) && !(__hip_atomic_load(&s_qw[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) & 0x20000)) {
                             if (w < 4 && (polls & 31) == 8 + 4 * w) halo_poll();
                             if (halo_refresh()) break;                         // (back to the wake bits: this wave is not idle any more)
                         }
@@ -2550,7 +2574,7 @@ int Engine::owned_phase() {
     P.own_flags = owned_flags;
     // (measured with the helping workgroups in place: FD 4096^2 15.9-16.3 ms with 8 waves against 16.5-16.8 with 16, 2048^2 7.25 against 6.44,
     //  SG 2048^2 7.08 against 6.55, 1024^2 3.40 against 2.84; MS-DFM, whose visits are longer and which has no early hand-off, 2048^2 13.1 against 15.0)
-    const bool half = owned_waves == 8 || (owned_waves == 0 && (nmaps > 1 || P.NTm > (algo == UFM_ALGO_DFM ? 12000 : 50000)));
+    const bool half = T == 16 && (owned_waves == 8 || (owned_waves == 0 && (nmaps > 1 || P.NTm > (algo == UFM_ALGO_DFM ? 12000 : 50000))));
     own_layout(half ? 5 : 4);
     k_own_import<<<64, 256, 0, stream>>>(P, k);
     // 16 waves per tile visit, one visit per CU -- or 8 and two: a visit is then ~17 % longer and a CU makes 1.7 x as many.  That pays
@@ -2563,10 +2587,15 @@ int Engine::owned_phase() {
         for (auto &e : own_ev) if (!e) HIPCHK(hipEventCreate(&e));
         own_timed = true;
     }
+#if UFM_TILE == 16
 #define UFM_LAUNCH(A) do { if (own_timed) { if (half) hipExtLaunchKernelGGL((k_relax<A, MODE_LOWER, false, 2>), g, b, 0, stream, own_ev[0], own_ev[1], 0, P, k, delta, INFINITY, ms_); \
                                                 else hipExtLaunchKernelGGL((k_relax<A, MODE_LOWER, false, 1>), g, b, 0, stream, own_ev[0], own_ev[1], 0, P, k, delta, INFINITY, ms_); } \
                            else if (half) k_relax<A, MODE_LOWER, false, 2><<<g, b, 0, stream>>>(P, k, delta, INFINITY, ms_); \
                            else k_relax<A, MODE_LOWER, false, 1><<<g, b, 0, stream>>>(P, k, delta, INFINITY, ms_); } while (0)
+#else   // 32 x 32 tiles: the 16-wave form only (the skewed 8-wave patch map is written for 4 x 4 patches per tile)
+#define UFM_LAUNCH(A) do { if (own_timed) hipExtLaunchKernelGGL((k_relax<A, MODE_LOWER, false, 1>), g, b, 0, stream, own_ev[0], own_ev[1], 0, P, k, delta, INFINITY, ms_); \
+                           else k_relax<A, MODE_LOWER, false, 1><<<g, b, 0, stream>>>(P, k, delta, INFINITY, ms_); } while (0)
+#endif
     if (algo == UFM_ALGO_FD) UFM_LAUNCH(UFM_ALGO_FD);
     else if (algo == UFM_ALGO_SG) UFM_LAUNCH(UFM_ALGO_SG);
     else if (opt_lvl == 0) UFM_LAUNCH(UFM_ALGO_DFM);
@@ -3421,6 +3450,13 @@ struct ufm_batch { std::vector<Engine *> shards; int n_maps = 0, per = 1; };
 
 extern "C" {
 
+#ifdef UFM_SWEEPSTAT
+int ufm_debug_sstat(unsigned long long *out, int reset) {
+    if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(g_sstat), sizeof(unsigned long long) * 32) != hipSuccess) return UFM_ERR_HIP_BASE;
+    if (reset) { unsigned long long z[32] = {}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_sstat), z, sizeof(z)) != hipSuccess) return UFM_ERR_HIP_BASE; }
+    return UFM_OK;
+}
+#endif
 #ifdef UFM_TIMING
 int ufm_debug_trace(unsigned long long *out, int cap) {     // returns the number of records copied (4 words each)
     unsigned int n = 0;

@@ -21,7 +21,7 @@
 #ifndef UFM_REGION_IDLE_SLEEP
 #define UFM_REGION_IDLE_SLEEP 16          // an idle wave of the block kernel looks at its wake words this often (x 64 clocks): 1 / 4 / 16 / 32 / 64 -> 100 replans 18.9 / 18.0 / 17.6 / 17.6 / 17.8 ms (the looks of twelve idle waves take issue slots and LDS cycles from the four that sweep)
 #endif
-constexpr int RTMAX = 10;                 // block edge in tiles
+constexpr int RTMAX = 160 / T;            // block edge in tiles (10 for 16 x 16 tiles)
 constexpr int RN = RTMAX * T;             // ... in elements (160)
 constexpr int RP = RN + 8;                // LDS pitch of the block's field: rows 4 apart on distinct banks (168 = 5*32 + 8)
 constexpr int RCP = RN + 4;               // pitch of the cost bytes
