@@ -119,7 +119,7 @@ int ufm_check_layout(ufm_t *p, uint64_t *bad_ring_entries, uint64_t *bad_cost_by
  * start's key and keep the rest queued for later steps, like the reference's priority queue;
  * 0 converges the whole field every step (every element then holds its final value).
  * "region" (default 1): replans run in one workgroup on an LDS-resident block of tiles around the patch
- * ("region_tiles" per side, goal-side edge "region_ahead" tiles beyond the patch centre); 0: launch chain only.
+ * ("region_tiles" per side, at most 8, goal-side edge "region_ahead" tiles beyond the patch centre); 0: launch chain only.
  * "owned" (default 1): a step that (re)initialises a search runs its lowering phase as ONE resident launch -- 256
  * workgroups, each serving the tiles it owns from one queue word per tile -- instead of a launch per ordering band
  * ("owned_band": its band in tile crossings; "owned_limit_ms": it hands back to the launch chain after this long,
@@ -131,12 +131,26 @@ int ufm_set_param(ufm_t *p, const char *name, double value);
 
 /* ---- back-pointers: the `Info` member of a level-1/2 map element (ExpandedMap.h:27-29; set in
  * FieldDPlanner_impl.h:86-111, ShiftedGridPlanner_impl.h:131-166, DynamicFastMarching_impl.h:73-99).
- * Not stored by the engine: derived on demand from the field as min_rhs<level>() derives them
- * (FD impl:196-208, SG :266-303, DFM :212-268).  info: int32 [nx][ny][2].  Node planners: [0] =
- * linear index (x * field_ny + y) of the node b with RHS(s) = cost over the edge (b, ccw_neighbor(s, b)),
- * [1] = -1.  DFM: the two cells of the winning stencil (-1: none, -2: outside the grid).
- * UFM_ERR_INVALID for a level-0 planner (its map has no Info). ---- */
+ * Stored by the engine, one byte per element, written with every value it writes: which candidate of the update
+ * operator produced the value.  The invalidation of a replan follows them (an element whose parent triangle no
+ * longer reproduces its value is gone, FD impl:100-110); ufm_read_info returns them in the reference's format.
+ * info: int32 [nx][ny][2].  Node planners: [0] = linear index (x * field_ny + y) of the node b with
+ * RHS(s) = cost over the edge (b, ccw_neighbor(s, b)), [1] = -1.  DFM: the two cells compute_optimal_cost
+ * leaves for the winning candidate (-1: none, -2: outside the grid).  (-1, -1) for the goal and for elements
+ * without a value.  UFM_ERR_INVALID for a level-0 planner (its map has no Info).
+ * ufm_read_info_derived: the same, derived from the field alone as min_rhs<level>() derives it (FD impl:196-208,
+ * SG :266-303, DFM :212-268) -- the checker of the stored ones; the two may differ where candidates tie. ---- */
 int ufm_read_info(ufm_t *p, int x0, int y0, int nx, int ny, int32_t *info);
+int ufm_read_info_derived(ufm_t *p, int x0, int y0, int nx, int ny, int32_t *info);
+/* Self-check of the stored back-pointers (node planners; UFM_ERR_INVALID for MS-DFM, whose invalidation does not use them), over the
+ * whole field: out[0] = elements that hold a value (the goal aside), out[1] = of those without a back-pointer, out[2] = elements BELOW
+ * their map's start key whose parent triangle, evaluated on the field as it stands, gives a larger value than the element holds
+ * (unsupported), out[3] = whose recorded dependence (on the triangle's edge / diagonal vertex) is not the one that evaluation has,
+ * out[4] = whose parent gives a smaller value (elements waiting to be lowered: beyond the start's key in a focused search, none
+ * otherwise), out[5] = unsupported elements at / beyond the start's key (invalidations a focused search keeps queued, like the
+ * reference's queue entries beyond its end condition).  out[1..3] must be 0 whenever no step is running: the invalidation of a
+ * replan follows these bytes without evaluating anything. */
+int ufm_check_info(ufm_t *p, uint64_t out[6]);
 
 /* ---- path extraction: replaces LinearInterpolationPathExtractor::extract_path
  * (PathExtraction/LinearInterpolationPathExtractor_impl.h:11-58) and the traversal case tables it
@@ -190,6 +204,7 @@ int ufm_batch_step(ufm_batch_t *b, ufm_stats *stats);
 int ufm_batch_read_field(ufm_batch_t *b, int i, int x0, int y0, int nx, int ny, float *g, float *rhs);
 int ufm_batch_read_map(ufm_batch_t *b, int i, uint8_t *host_map);
 int ufm_batch_check_layout(ufm_batch_t *b, uint64_t *bad_ring_entries, uint64_t *bad_cost_bytes);
+int ufm_batch_check_info(ufm_batch_t *b, uint64_t out[6]);                 /* as ufm_check_info, summed over the maps */
 int ufm_batch_set_param(ufm_batch_t *b, const char *name, double value);   /* as ufm_set_param */
 int ufm_batch_set_profiling(ufm_batch_t *b, int enable);
 void *ufm_batch_stream(ufm_batch_t *b, int shard);                         /* hipStream_t of shard's engine */

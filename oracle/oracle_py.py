@@ -61,6 +61,8 @@ def lib():
         L.orc_min_rhs_info.restype = f
         L.orc_min_rhs_info.argtypes = [vp, i, i, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
         L.orc_load_g.argtypes = [vp, vp]
+        L.orc_cost_via.restype = f
+        L.orc_cost_via.argtypes = [vp, i, i, i, i, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
         _LIB = L
     return _LIB
 
@@ -171,6 +173,13 @@ class OraclePlanner:
                 self.L.orc_min_rhs_info(self.h, x, y, C.byref(a), C.byref(b))
                 out[x, y, 0], out[x, y, 1] = a.value, b.value
         return out
+
+    def cost_via(self, x, y, bx, by):
+        """(cost, b0, b1) through a given back-pointer on the current G field: node planners the node (bx, by) with its ccw
+        neighbour, DFM the level-1 candidate built on the neighbour cell (bx, by)"""
+        a, b = C.c_int32(), C.c_int32()
+        c = self.L.orc_cost_via(self.h, int(x), int(y), int(bx), int(by), C.byref(a), C.byref(b))
+        return float(np.float32(c)), a.value, b.value
 
     def threshold_uchar(self):
         return self.L.orc_threshold_uchar(self.h)

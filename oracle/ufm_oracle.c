@@ -835,5 +835,20 @@ float orc_min_rhs_info(const orc_t *p, int x, int y, int32_t *b0, int32_t *b1) {
     *b0 = a; *b1 = b;
     return rhs;
 }
+/* The cost through a GIVEN back-pointer on the current G field (checker of the engine's stored back-pointers, which may name
+ * another candidate than min_rhs where two of them tie).  Node planners: compute_optimal_cost(s, b, ccw_neighbor(s, b))
+ * (FieldDPlanner_impl.h:200-205); *b0 = b, *b1 = -1.  DFM: the level-1 candidate built on the neighbour cell (bx, by),
+ * min_rhs_decreased_neighbor (DynamicFastMarching_impl.h:270-313), with the pair of cells it leaves. */
+float orc_cost_via(const orc_t *p, int x, int y, int bx, int by, int32_t *b0, int32_t *b1) {
+    int a = -1, b = -1;
+    float c = INFINITY;
+    if (p->algo == ORC_ALGO_DFM) c = dfm_min_rhs_decreased_neighbor(p, x, y, bx, by, &a, &b);
+    else if (valid_elem(p, bx, by)) {
+        int cx, cy;
+        if (ccw_neighbor(p, x, y, bx, by, &cx, &cy)) { c = coc(p, x, y, bx, by, cx, cy); a = eidx(p, bx, by); }
+    }
+    *b0 = a; *b1 = b;
+    return c;
+}
 /* test hook: overwrite the G field (e.g. with one read back from the engine) */
 void orc_load_g(orc_t *p, const float *g) { memcpy(p->g, g, p->n * sizeof(float)); }

@@ -85,6 +85,8 @@ int orc_threshold_uchar(const orc_t *p);
 /* back-pointer(s) min_rhs<1/2> derives from the current G field (a pure function of it), and a
  * test hook that loads a G field */
 float orc_min_rhs_info(const orc_t *p, int x, int y, int32_t *b0, int32_t *b1);
+/* cost through a given back-pointer (node planners: node b; DFM: neighbour cell of the level-1 candidate) on the current G field */
+float orc_cost_via(const orc_t *p, int x, int y, int bx, int by, int32_t *b0, int32_t *b1);
 void orc_load_g(orc_t *p, const float *g);
 
 #ifdef __cplusplus

@@ -9,7 +9,9 @@
 #include <cstdlib>
 #include <cstring>
 #include <memory>
+#include <cmath>
 #include <string>
+#include <type_traits>
 #include <vector>
 
 #define NO_HEURISTIC
@@ -62,7 +64,18 @@ int run(int size, const std::vector<uint8_t> &raster, int n_patches, const std::
       auto info = std::get<2>(e.second);      // the level-1/2 planners' back-pointer member (ExpandedMap.h:27-29)
       (void)info;
     }
-  std::printf("dump size %lld iterated %lld sum_g %.6f\n", n, cnt, sum);
+  // ... against the same field probed element by element through the map's read accessors (what the path extractor does):
+  // the elements that hold a value beyond the start's key are not final and not the same from run to run, so the dump is
+  // held to the process's own field, not to another run's
+  const int ex = std::is_same<Elem, Cell>::value ? size : size + 1;
+  long long probed = 0;
+  double psum = 0;
+  for (int x = 0; x < ex; ++x)
+    for (int y = 0; y < ex; ++y) {
+      const float v = map.get_g(Elem(x, y));
+      if (v < INFINITY) { ++probed; psum += v; }
+    }
+  std::printf("dump size %lld iterated %lld sum_g %.6f probed %lld probed_sum %.6f\n", n, cnt, sum, probed, psum);
   return 0;
 }
 

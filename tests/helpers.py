@@ -71,6 +71,11 @@ def check_parity(o, g, what="", below_start_key=False):
     assert np.array_equal(grhs[mask], gg[mask])
     # the engine's redundant copies (neighbour rings, cost windows) agree with their originals
     assert g.check_layout() == (0, 0), "%s: layout self-check %r" % (what, g.check_layout())
+    # ... and the stored back-pointers name, for every element that holds a value, a parent triangle that gives that value (the invalidation
+    # of the node planners follows them without evaluating anything)
+    if o.algo != 2:
+        ci = g.check_info()
+        assert ci[1:4] == (0, 0, 0), "%s: back-pointer self-check %r" % (what, ci)
     return n, nbad
 
 

@@ -68,10 +68,14 @@ def test_driver_matches_python_binding(tmp_path, algo):
         if algo != "DFM":
             assert np.float32(m.group(4)) == g[sx, sy]
         assert float(m.group(6)) == float(cur[top, left])     # the host-side Graph mirror followed the patch
-    m = re.match(r"dump size (\d+) iterated (\d+) sum_g (\S+)", lines[-1])
+    # the `tof` dump: map.size() == elements iterated over map.buckets == elements with a value when the field is probed through
+    # get_g, in the driver's own process (elements beyond the start's key are not final: which of them hold a value is not
+    # the same from run to run, so another run's count is only a sanity bound)
+    m = re.match(r"dump size (\d+) iterated (\d+) sum_g (\S+) probed (\d+) probed_sum (\S+)", lines[-1])
     g = p.g()
-    assert int(m.group(1)) == int(m.group(2)) == int(np.isfinite(g).sum())
-    assert abs(float(m.group(3)) - float(g[np.isfinite(g)].astype(np.float64).sum())) <= 1e-6 * float(m.group(3))
+    assert int(m.group(1)) == int(m.group(2)) == int(m.group(4))
+    assert abs(float(m.group(3)) - float(m.group(5))) <= 1e-9 * float(m.group(3))
+    assert abs(int(m.group(1)) - int(np.isfinite(g).sum())) <= 0.1 * int(m.group(1))
     p.close()
 
 

@@ -633,31 +633,62 @@ def test_config4_batch_of_8_maps_2048_dfm():
 
 @pytest.mark.parametrize("algo,lvl", [("FD", 1), ("SG", 1), ("SG", 2), ("DFM", 1)])
 def test_back_pointer_view(algo, lvl):
-    """ufm_read_info: the reference's INFO (back-pointers of the level-1/2 planners) derived from the
-    field.  Checked against the oracle's min_rhs<level> evaluated on the very same field (loaded into
-    the oracle), element by element, after a plan and some replans; a level-0 planner has no Info."""
+    """ufm_read_info: the reference's INFO (back-pointers of the level-1/2 planners).  Three views of it, after a plan and
+    some replans: the engine's STORED ones (one byte per element, written with every value; the invalidation follows them),
+    the ones the engine DERIVES from the field alone, and the oracle's min_rhs<level> evaluated on the very same field
+    (loaded into the oracle).  Derived == oracle element by element.  Stored: every element the step finalised has one,
+    and the candidate it names reproduces the element's value bit for bit (orc_cost_via); it names the same neighbour as
+    the derived view except where two candidates tie.  A level-0 planner has no Info."""
     width, length = 120, 88
     cost = ufm_amd.synth.cost_map(17, width, length)
     start, goal = ufm_amd.synth.start_goal(width, length)
     o, g = make_pair(ALGOS[algo], lvl, cost, start, goal)
-    assert g.step() == 0
+    assert g.step() == 0 and o.step() == 0
     for k, s, top, left, patch in ufm_amd.synth.replan_script(17, width, length, n_patches=3, size=15):
         g.patch_map(patch, top, left); o.patch_map(patch, top, left)
-        g.set_start(*s)
-        assert g.step() == 0
+        g.set_start(*s); o.set_start(*s)
+        assert g.step() == 0 and o.step() == 0
+    final = o.trusted_mask(below_start_key=True)      # what the planners guarantee final
     field = g.g()
     o.load_g(field)                       # same raster (patched above), same field
     ref = o.info_field()
-    got = g.read_info()
+    got = g.read_info(derived=True)
     assert got.shape == ref.shape
     bad = np.argwhere((got != ref).any(axis=2))
     assert len(bad) == 0, "%d of %d elements differ, first %r: engine %r oracle %r" % (
         len(bad), got.shape[0] * got.shape[1], tuple(bad[0]), got[tuple(bad[0])].tolist(), ref[tuple(bad[0])].tolist())
     # the view says something: most reached elements have a back-pointer
     assert (got[..., 0] >= 0).sum() > 0.8 * np.isfinite(field).sum()
+    # ---- the stored back-pointers ----
+    sto = g.read_info()
+    gx, gy = int(round(goal[0])), int(round(goal[1]))
+    check = final & np.isfinite(field)
+    check[gx, gy] = False                 # the goal has none
+    assert (sto[..., 0][check] >= 0).all(), "%d finalised elements without a stored back-pointer" % int((sto[..., 0][check] < 0).sum())
+    same = (sto == got).all(axis=2)
+    # (they part where candidates tie, and ties are structural: along a grid edge both triangles over that edge cost g1 + min(c, b))
+    assert same[check].mean() > 0.8, "stored and derived back-pointers agree on only %.3f of the finalised elements" % same[check].mean()
+    ey = field.shape[1]
+    n_tie = 0
+    for x, y in np.argwhere(check):       # the named candidate reproduces the value (all of them; the ties are the interesting ones)
+        b0, b1 = int(sto[x, y, 0]), int(sto[x, y, 1])
+        if ALGOS[algo] == 2:              # DFM: one of the eight level-1 candidates leaves this pair and gives this value
+            ok = False
+            for dx in (-1, 0, 1):
+                for dy in (-1, 0, 1):
+                    if (dx or dy) and 0 <= x + dx < field.shape[0] and 0 <= y + dy < ey:
+                        c, a0, a1 = o.cost_via(x, y, x + dx, y + dy)
+                        ok = ok or (a0 == b0 and a1 == b1 and abs(c - float(field[x, y])) <= DFM_RTOL * float(field[x, y]))
+            assert ok, "DFM cell (%d, %d): no level-1 candidate leaves the stored pair (%d, %d) with value %r" % (x, y, b0, b1, float(field[x, y]))
+        else:
+            c, a0, _a1 = o.cost_via(x, y, b0 // ey, b0 % ey)
+            assert a0 == b0 and c == float(field[x, y]), "node (%d, %d): stored parent %d gives %r, the field holds %r" % (x, y, b0, c, float(field[x, y]))
+        n_tie += 0 if same[x, y] else 1
+    print("%s-%d: %d finalised elements, stored == derived on all but %d (ties)" % (algo, lvl, int(check.sum()), n_tie))
     # a window equals the same part of the whole
-    win = g.read_info(10, 20, 30, 40)
+    win = g.read_info(10, 20, 30, 40, derived=True)
     assert np.array_equal(win, got[10:40, 20:60])
+    assert np.array_equal(g.read_info(10, 20, 30, 40), sto[10:40, 20:60])
     z = ufm_amd.Planner(ALGOS[algo], 0)
     z.set_occupancy_threshold(1); z.set_map(cost); z.set_start(*start); z.set_goal(*goal)
     assert z.step() == 0

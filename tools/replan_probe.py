@@ -28,7 +28,7 @@ for rep in range(3):
         assert p.step() == 0
         times.append(time.perf_counter() - t); cells += p.stats.expanded; visits += p.stats.tile_visits; evals += p.stats.elem_evals
     ts = np.array(times) * 1e6
-    print("%s %d^2 %s: plan %.2f ms; 100 replans %.2f ms (median %.0f us, p90 %.0f, max %.0f); block kernel %d/%d done; cells %d visits %d patch-sweeps/replan %d launches(last) %d" % (
+    print("%s %d^2 %s: plan %.2f ms; 100 replans %.2f ms (median %.0f us, p90 %.0f, max %.0f); block kernel %d/%d done; cells %d visits %d patch-sweeps/replan %d launches(last) %d back-pointers %s" % (
         algo, size, params, t_plan * 1e3, ts.sum() / 1e3, np.median(ts), np.percentile(ts, 90), ts.max(),
-        p.stats.region_replans_done, p.stats.region_replans, cells, visits, evals // 1600, p.stats.launches), flush=True)
+        p.stats.region_replans_done, p.stats.region_replans, cells, visits, evals // 1600, p.stats.launches, p.check_info() if algo != "DFM" else "-"), flush=True)
     p.close()

@@ -20,8 +20,8 @@ SYMBOLS = [
     "ufm_version", "ufm_tile_edge", "ufm_batch_create", "ufm_batch_destroy", "ufm_batch_size",
     "ufm_batch_set_occupancy_threshold", "ufm_batch_set_map", "ufm_batch_patch_map",
     "ufm_batch_set_start", "ufm_batch_set_goal", "ufm_batch_reset", "ufm_batch_step",
-    "ufm_batch_read_field", "ufm_extract_path", "ufm_batch_extract_path", "ufm_read_info",
-    "ufm_check_layout", "ufm_batch_check_layout", "ufm_batch_set_param",
+    "ufm_batch_read_field", "ufm_extract_path", "ufm_batch_extract_path", "ufm_read_info", "ufm_read_info_derived",
+    "ufm_check_layout", "ufm_batch_check_layout", "ufm_batch_set_param", "ufm_check_info", "ufm_batch_check_info",
     "ufm_batch_create_sharded", "ufm_batch_shards", "ufm_batch_set_heuristic_multiplier", "ufm_batch_set_map_device",
     "ufm_batch_patch_map_device", "ufm_batch_read_map", "ufm_batch_set_profiling", "ufm_batch_stream",
 ]
@@ -115,6 +115,8 @@ def load_library():
     L.ufm_read_map.argtypes = [vp, vp]
     L.ufm_check_layout.argtypes = [vp, vp, vp]
     L.ufm_batch_check_layout.argtypes = [vp, vp, vp]
+    L.ufm_check_info.argtypes = [vp, vp]
+    L.ufm_batch_check_info.argtypes = [vp, vp]
     L.ufm_batch_set_param.argtypes = [vp, C.c_char_p, C.c_double]
     L.ufm_set_param.argtypes = [vp, C.c_char_p, C.c_double]
     L.ufm_set_profiling.argtypes = [vp, i]
@@ -142,6 +144,7 @@ def load_library():
     L.ufm_batch_step.argtypes = [vp, C.POINTER(Stats)]
     L.ufm_batch_read_field.argtypes = [vp, i, i, i, i, i, vp, vp]
     L.ufm_read_info.argtypes = [vp, i, i, i, i, vp]
+    L.ufm_read_info_derived.argtypes = [vp, i, i, i, i, vp]
     L.ufm_extract_path.argtypes = [vp, i, i, i, vp, i, vp, i, C.POINTER(PathInfo)]
     L.ufm_batch_extract_path.argtypes = [vp, i, i, i, vp, i, vp, i, C.POINTER(PathInfo)]
     _LIB = L
@@ -251,13 +254,15 @@ class Planner:
     def g(self):
         return self.read_field()[0]
 
-    def read_info(self, x0=0, y0=0, nx=None, ny=None):
-        """back-pointers (the reference's INFO of level-1/2 planners) derived from the field: int32 [nx][ny][2]"""
+    def read_info(self, x0=0, y0=0, nx=None, ny=None, derived=False):
+        """back-pointers (the reference's INFO of level-1/2 planners): int32 [nx][ny][2] -- the stored ones, or
+        (derived=True) those min_rhs<level>() derives from the field alone"""
         ex, ey = self.dims()
         nx = ex - x0 if nx is None else nx
         ny = ey - y0 if ny is None else ny
         out = np.empty((nx, ny, 2), np.int32)
-        _chk(self.L.ufm_read_info(self.h, x0, y0, nx, ny, out.ctypes.data), "ufm_read_info")
+        fn = self.L.ufm_read_info_derived if derived else self.L.ufm_read_info
+        _chk(fn(self.h, x0, y0, nx, ny, out.ctypes.data), "ufm_read_info")
         return out
 
     def extract_path(self, max_steps=20, lookahead=True, allow_indirect=True):
@@ -284,6 +289,15 @@ class Planner:
         bad = (C.c_uint64 * 2)()
         _chk(self.L.ufm_check_layout(self.h, C.addressof(bad), C.addressof(bad) + 8), "ufm_check_layout")
         return int(bad[0]), int(bad[1])
+
+
+    def check_info(self):
+        """stored back-pointers (node planners): (elements with a value, without a back-pointer, whose parent triangle does not
+        give the value but a larger one, whose dependence bits are off, whose parent gives a smaller value -- waiting to be
+        lowered, beyond the start's key --, unsupported ones at / beyond the start's key: queued invalidations); [1:4] are 0 when sound"""
+        out = (C.c_uint64 * 6)()
+        _chk(self.L.ufm_check_info(self.h, C.addressof(out)), "ufm_check_info")
+        return tuple(int(v) for v in out)
 
 
 class BatchPlanner:
@@ -391,6 +405,11 @@ class BatchPlanner:
 
     def set_param(self, name, value):
         _chk(self.L.ufm_batch_set_param(self.h, name.encode(), float(value)), "ufm_batch_set_param")
+
+    def check_info(self):
+        out = (C.c_uint64 * 6)()
+        _chk(self.L.ufm_batch_check_info(self.h, C.addressof(out)), "ufm_batch_check_info")
+        return tuple(int(v) for v in out)
 
     def check_layout(self):
         bad = (C.c_uint64 * 2)()

@@ -188,6 +188,8 @@ struct DevDyn {
 struct DevParams {
     float *G;                   // [NT][T][T] tile-major; elements of a tile beyond the map stay +inf
     float *Gprev;               // snapshot of a tile at its first touch in a step (same layout)
+    uint8_t *bp;                // [NT][T][T] back-pointers (the level-1/2 planners' INFO, FD impl:86-111, SG :131-166, DFM :73-99), same layout as G: which of
+                                // the operator's candidates gives the element's value, and which of its inputs that leans on (bp_byte); BP_NONE: goal / never set
     float *ring;                // [NT][RING] border values of each tile's eight neighbours (+inf where there is none)
     uint8_t *cost;              // [nmaps][L][W] the raster (Graph::map_)
     uint8_t *costT;             // [NT][CTS] per tile, the cost bytes its visit needs: cells (x0-1..x0+T-1, y0-1..y0+T-1) of a
@@ -559,6 +561,93 @@ __device__ __forceinline__ float quad_min(float v) {
 #endif
 }
 
+// Back-pointers (DevParams::bp), one byte per element: (code << 2) | dep.  Written once per step, when it has converged, for every tile the step
+// touched (k_finalize_bp; the block kernel of a replan does it for the tiles it changed, ufm_region.h): one evaluation of the operator on the
+// final values with the arg-min kept -- not in the sweeps, where tracking the winner cost the plan 9 % and still left bytes behind whose
+// triangle no longer gave the value (the operator's case analysis is not monotone).
+// code, node planners: (q << 1) | h -- the triangle of cell q (the quad lane that evaluated it) whose edge neighbour p1 is the vertical (h = 0) or the
+// horizontal one (h = 1); its other vertex p2 is the diagonal node of that cell.  MS-DFM level 0: the stencil (0 orthogonal, 1 diagonal); level 1:
+// (q << 1) | which of the axis's two neighbours (0: -so, 1: +so).  Of several candidates that tie, the lowest code.
+// dep, node planners: which of the two vertices the value depends on -- bit 0: G(p1), bit 1: G(p2) -- by the case compute_optimal_cost took
+// (FD impl:292-319, SG :422-436): "g1 + ..." (III, B) leans on p1 alone, "g2 + ..." (I, A) on p2 alone, the interpolated case (II) on both.  With the other
+// vertex at +inf the same case is taken and gives the same value, so: an element is gone exactly when a vertex it depends on is gone (the invalidation of
+// ufm_region.h follows these bits without evaluating anything).  MS-DFM: 3.
+constexpr int BP_NONE = 0xFF;
+__device__ __forceinline__ int dep_sg(float g1, float g2, const CellSG &K) {
+    const float f = g1 - g2;
+    return (f <= 0.0f) ? 1 : ((f * SQRT2F <= K.ccmp) ? 3 : 2);
+}
+__device__ __forceinline__ int dep_fd(float g1, float g2, const CellFD &K, const TriFD &Q) {
+    const float f = g1 - g2, ff = f * f;
+    return ((f <= 0.0f) | (ff <= Q.cbp)) ? 1 : (((f <= Q.bp) & (K.c > f * SQRT2F)) ? 3 : ((f > Q.bI) ? 2 : 2));
+}
+// A lane's evaluation with what the back-pointer needs: r = the smaller of the lane's candidates, h = it was the second one, and (node planners) the
+// three neighbour values it was computed from.
+struct LaneEval { float r; bool h; float gV, gH, gD; };
+template <int ALGO, int GPITCH = GP>
+__device__ __forceinline__ LaneEval eval_quad_w(const float *ctr, int q, const QuadConsts<ALGO> &C) {
+    LaneEval e;
+    e.gV = e.gH = e.gD = 0.0f;
+    if constexpr (ALGO == UFM_ALGO_DFM) {
+        e.r = INFINITY;
+        if (q < 2) {
+            const int a = q ? -GPITCH - 1 : -GPITCH, b = q ? GPITCH + 1 : GPITCH, c = q ? GPITCH - 1 : -1, d = q ? -GPITCH + 1 : 1;
+            e.r = q_dfm(fminf(ctr[a], ctr[b]), fminf(ctr[c], ctr[d]), C.th);
+        }
+        e.h = false;
+    } else if constexpr (ALGO == ALGO_DFM1) {
+        const float pm = fminf(ctr[-C.po], ctr[C.po]);
+        const float a = q_dfm(ctr[-C.so], pm, C.th), b = q_dfm(ctr[C.so], pm, C.th);
+        e.h = b < a;
+        e.r = e.h ? b : a;
+    } else {
+        const int sx = (q & 2) ? GPITCH : -GPITCH, sy = (q & 1) ? 1 : -1;
+        e.gD = ctr[sx + sy]; e.gV = ctr[sx]; e.gH = ctr[sy];
+        float tV, tH;
+        if constexpr (ALGO == UFM_ALGO_SG) { tV = tri_sg(e.gV, e.gD, C.k); tH = tri_sg(e.gH, e.gD, C.k); }
+        else { tV = tri_fd(e.gV, e.gD, C.k, C.tv); tH = tri_fd(e.gH, e.gD, C.k, C.th); }
+        e.h = tH < tV;
+        e.r = e.h ? tH : tV;
+    }
+    return e;
+}
+// ... and the byte for a lane that holds the quad's minimum (0x3FF for one that does not: the quad's smallest is the lowest winning code)
+template <int ALGO>
+__device__ __forceinline__ int bp_byte(const LaneEval &e, int q, const QuadConsts<ALGO> &C, bool winner) {
+    int code, dep = 3;
+    if constexpr (ALGO == UFM_ALGO_DFM) code = q;
+    else code = (q << 1) | (e.h ? 1 : 0);
+    if constexpr (ALGO == UFM_ALGO_SG) dep = dep_sg(e.h ? e.gH : e.gV, e.gD, C.k);
+    if constexpr (ALGO == UFM_ALGO_FD) {
+        TriFD t;
+        t.bp = e.h ? C.th.bp : C.tv.bp; t.cbp = e.h ? C.th.cbp : C.tv.cbp; t.bI = e.h ? C.th.bI : C.tv.bI;
+        dep = dep_fd(e.h ? e.gH : e.gV, e.gD, C.k, t);
+    }
+    return winner ? ((code << 2) | dep) : 0x3FF;
+}
+__device__ __forceinline__ int quad_min_int(int v) {
+    v = min(v, __builtin_amdgcn_update_dpp(v, v, 0xB1, 0xF, 0xF, false));   // quad_perm [1,0,3,2]
+    return min(v, __builtin_amdgcn_update_dpp(v, v, 0x4E, 0xF, 0xF, false)); // quad_perm [2,3,0,1]
+}
+// Node planners, invalidation: the value the element's OWN parent triangle (stored byte bpb) gives now -- what the reference's level-1/2 planners
+// look at when a neighbour is raised (FD impl:100-110: only elements whose back-pointer involves the raised node are recomputed).  +inf from the
+// lanes of the other cells (and from every lane when there is no parent: the quad's min is then +inf, and a finite value without a parent goes).
+template <int ALGO, int GPITCH = GP>
+__device__ __forceinline__ float eval_quad_bp(const float *ctr, int q, const QuadConsts<ALGO> &C, int bpb) {
+    static_assert(ALGO == UFM_ALGO_FD || ALGO == UFM_ALGO_SG, "node planners");
+    const int bpc = bpb >> 2;
+    const int sx = (q & 2) ? GPITCH : -GPITCH, sy = (q & 1) ? 1 : -1;
+    const bool h = bpc & 1;
+    const float gD = ctr[sx + sy], g1 = ctr[h ? sy : sx];
+    float r;
+    if constexpr (ALGO == UFM_ALGO_SG) r = tri_sg(g1, gD, C.k);
+    else {
+        TriFD t;
+        t.bp = h ? C.th.bp : C.tv.bp; t.cbp = h ? C.th.cbp : C.tv.cbp; t.bI = h ? C.th.bI : C.tv.bI;
+        r = tri_fd(g1, gD, C.k, t);
+    }
+    return (bpc >> 1) == q ? r : INFINITY;
+}
 // ctr points at the node inside the LDS tile; returns this lane's share of RHS(node)
 template <int ALGO, int GPITCH = GP>
 __device__ __forceinline__ float eval_quad(const float *ctr, int q, const QuadConsts<ALGO> &C) {
@@ -676,6 +765,7 @@ __global__ __launch_bounds__(OWNK == 2 ? NTHR / 2 : NTHR, UFM_RELAX_WAVES) void 
 #ifdef UFM_TIMING
     __shared__ unsigned int s_misc_vi;
 #endif
+    __shared__ uint8_t Bs[(MODE == MODE_RAISE && !is_dfm<ALGO>) ? TT : 1];   // the tile's back-pointer bytes (invalidation of the node planners)
     __shared__ int s_qw[2];       // in-visit refresh: [0] this tile's queue word as an idle wave last saw it (loaded straight into LDS), [1] refreshes of this visit
 
     const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
@@ -1046,6 +1136,8 @@ __global__ __launch_bounds__(OWNK == 2 ? NTHR / 2 : NTHR, UFM_RELAX_WAVES) void 
         const float gl0 = ld_f<OWN>(&Gt[io_on ? tid : 0]);
         const float hv = ld_f<OWN>(&ring[ht >= 0 ? ht : 0]);
         const int c0 = ct[tid < CN ? tid : 0];
+        constexpr bool BPRAISE = MODE == MODE_RAISE && !is_dfm<ALGO>;   // invalidation along the stored back-pointers
+        const int bp0 = BPRAISE ? P.bp[(size_t)gt * TT + (io_on ? tid : 0)] : BP_NONE;
         const int goal_x = P.goal[2 * m], goal_y = P.goal[2 * m + 1];   // (with the rest: read after the barrier they cost two more round trips)
         // resident kernel: the values of the map's start elements, one per lane (for the end condition below)
         const int own_sa = (OWN && focused && tid < 4 && m < 64) ? s_se[m * 4 + tid] : -1;
@@ -1080,6 +1172,7 @@ __global__ __launch_bounds__(OWNK == 2 ? NTHR / 2 : NTHR, UFM_RELAX_WAVES) void 
 
         // the tile (contiguous) and its halo: the ring record, in this order (RING_*)
         if (io_on) Gs[(io_r + 1) * GP + io_c + 1] = gl0;
+        if (BPRAISE && io_on) Bs[tid] = (uint8_t)bp0;
         if (ht >= 0) {
             int hr, hc;
             if (ht < T) { hr = -1; hc = ht; }
@@ -1234,7 +1327,7 @@ __global__ __launch_bounds__(OWNK == 2 ? NTHR / 2 : NTHR, UFM_RELAX_WAVES) void 
 
         // per-lane constants of the wave's four patches
         QuadConsts<ALGO> C[PPWK];
-        int off[PPWK], wword[PPWK], wbit[PPWK];
+        int off[PPWK], wword[PPWK], wbit[PPWK], bpc[PPWK];
         bool goal[PPWK];
 #pragma unroll
         for (int j = 0; j < PPWK; ++j) {
@@ -1244,6 +1337,7 @@ __global__ __launch_bounds__(OWNK == 2 ? NTHR / 2 : NTHR, UFM_RELAX_WAVES) void 
             const int lx = pr_ * 4 + (nd >> 2), ly = pc_ * 4 + (nd & 3);
             C[j].load(Cs, lx, ly, q);
             off[j] = (lx + 1) * GP + ly + 1;
+            bpc[j] = BPRAISE ? Bs[lx * T + ly] : BP_NONE;
             goal[j] = (x0 + lx == goal_x) & (y0 + ly == goal_y);
             wword[j] = 0; wbit[j] = 0;
             if (lane < 9) {
@@ -1373,7 +1467,10 @@ __global__ __launch_bounds__(OWNK == 2 ? NTHR / 2 : NTHR, UFM_RELAX_WAVES) void 
 #endif
                     for (int b = 0; b < 16 && again; ++b) {
                         asm volatile("" ::: "memory");   // re-read the LDS tile every sweep (other waves and lanes write it)
-                        float nv = quad_min(eval_quad<ALGO>(ctr, q, C[j]));
+                        float rl;                        // this lane's candidate
+                        if constexpr (BPRAISE) rl = eval_quad_bp<ALGO>(ctr, q, C[j], bpc[j]);
+                        else rl = eval_quad<ALGO>(ctr, q, C[j]);
+                        float nv = quad_min(rl);
                         if (goal[j]) nv = 0.0f;          // RHS(goal) = 0, *_impl.h init()
                         bool want, doit;
                         if (MODE == MODE_LOWER) {
@@ -2015,6 +2112,56 @@ __global__ void k_check_layout(DevParams P, unsigned long long *out) {
     if (bad_ring) atomicAdd(&out[0], bad_ring);
     if (bad_cost) atomicAdd(&out[1], bad_cost);
 }
+// Self-check of the stored back-pointers (ufm_check_info), node planners: every element that holds a value (but the goal) must name a parent
+// triangle, that triangle must give the element's value when it is evaluated on the field as it stands -- bit for bit, with the operator the
+// sweeps use -- and the dep bits must say which vertices that evaluation leans on.  The invalidation follows these bytes blindly (ufm_region.h),
+// so this is the invariant it rests on.  out[0]: elements with a value, out[1]: without a parent, out[2]: whose parent gives a LARGER value
+// (an unsupported element) although the element lies below its map's start key: never; out[3]: whose dep bits differ from the case the evaluation
+// takes; out[4]: whose parent gives a smaller value (an element waiting to be lowered: beyond the start's key in a focused search, nowhere
+// otherwise); out[5]: unsupported elements at or beyond the start's key (invalidations a focused search keeps queued, like the reference's
+// under-consistent queue entries beyond its end condition).
+template <int ALGO>
+__global__ void k_check_bp(DevParams P, unsigned long long *out) {
+    unsigned long long n_val = 0, n_none = 0, n_bad = 0, n_dep = 0, n_low = 0, n_parked = 0;
+    const int thr = P.dyn->thr;
+    const size_t n = (size_t)P.nmaps * P.EX * P.EY;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const int m = (int)(i / ((size_t)P.EX * P.EY)), e = (int)(i - (size_t)m * P.EX * P.EY), x = e / P.EY, y = e - x * P.EY;
+        const float g = P.G[gaddr(P, m, x, y)];
+        if (!(g < INFINITY) || (x == P.goal[2 * m] && y == P.goal[2 * m + 1])) continue;
+        ++n_val;
+        const int b = P.bp[gaddr(P, m, x, y)];
+        if (b == BP_NONE) { ++n_none; continue; }
+        const int q = (b >> 3) & 3, h = (b >> 2) & 1, dx = (q & 2) ? 1 : -1, dy = (q & 1) ? 1 : -1;
+        auto val = [&](int ex, int ey) { return (ex >= 0 && ey >= 0 && ex < P.EX && ey < P.EY) ? P.G[gaddr(P, m, ex, ey)] : INFINITY; };
+        auto cst = [&](int cx, int cy) {
+            if (cx < 0 || cy < 0 || cx >= P.L || cy >= P.W) return INFINITY;
+            const int c = P.cost[(size_t)m * P.cstride + (size_t)cx * P.W + cy];
+            return c >= thr ? INFINITY : (float)c;
+        };
+        const int cx = x - 1 + (q >> 1), cy = y - 1 + (q & 1);                  // the triangle's cell
+        const float c = cst(cx, cy), g1 = h ? val(x, y + dy) : val(x + dx, y), g2 = val(x + dx, y + dy);
+        float r; int dep;
+        if constexpr (ALGO == UFM_ALGO_SG) { CellSG k; k.set(c); r = tri_sg(g1, g2, k); dep = dep_sg(g1, g2, k); }
+        else {
+            const float bb = h ? cst(x - 1 + (1 - (q >> 1)), cy) : cst(cx, y - 1 + (1 - (q & 1)));   // the cell across the edge s-p1
+            CellFD k{c, c * c, c * SQRT2F}; TriFD t; t.set(c, bb);
+            r = tri_fd(g1, g2, k, t); dep = dep_fd(g1, g2, k, t);
+        }
+        if (r > g || r != r) {
+            const float B = P.dyn->focused ? start_bound(P, m) : INFINITY;
+            if (g + tile_heuristic(P, m, x / T, y / T) < B || B == INFINITY) ++n_bad; else ++n_parked;
+        }
+        else if (r < g) ++n_low;
+        else if (dep != (b & 3)) ++n_dep;
+    }
+    if (n_val) atomicAdd(&out[0], n_val);
+    if (n_none) atomicAdd(&out[1], n_none);
+    if (n_bad) atomicAdd(&out[2], n_bad);
+    if (n_dep) atomicAdd(&out[3], n_dep);
+    if (n_low) atomicAdd(&out[4], n_low);
+    if (n_parked) atomicAdd(&out[5], n_parked);
+}
 // mean traversable cost of a raster (sets the default ordering band)
 __global__ void k_cost_stats(const uint8_t *cm, size_t n, int thr, unsigned long long *out) {
     unsigned long long s = 0, c = 0;
@@ -2064,6 +2211,50 @@ __global__ __launch_bounds__(256) void k_finalize(DevParams P, int only_if_done)
     }
     for (int o = 32; o > 0; o >>= 1) total += __shfl_down(total, o);
     if (lane == 0 && total) atomicAdd(&P.ctr->expanded, total);
+}
+// The back-pointers of the tiles a step touched, once it has converged (see bp_byte): per tile one workgroup of four waves stages the tile, its
+// ring and its cost window as a visit does and evaluates every node once, four lanes per node, keeping the arg-min.
+template <int ALGO>
+__device__ void tile_bp(const DevParams &P, int gt, int thr, float *Gs, float *Cs) {      // all threads of a 256-thread workgroup call
+    constexpr int CROWS = is_dfm<ALGO> ? T : T + 1, COFF = is_dfm<ALGO> ? 0 : 1, CN = CROWS * CROWS;
+    const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63, q = lane & 3, nd = lane >> 2;
+    const int m = gt / P.NTm, t = gt - m * P.NTm, tx = t / P.TY, ty = t - tx * P.TY, x0 = tx * T, y0 = ty * T;
+    const float *Gt = P.G + (size_t)gt * TT, *ring = P.ring + (size_t)gt * RING;
+    const uint8_t *ct = P.costT + (size_t)gt * CTS;
+    for (int e = tid; e < TT; e += 256) Gs[(e / T + 1) * GP + e % T + 1] = Gt[e];
+    for (int ht = tid; ht < 4 * T + 4; ht += 256) {
+        int hr, hc;
+        if (ht < T) { hr = -1; hc = ht; }
+        else if (ht < 2 * T) { hr = T; hc = ht - T; }
+        else if (ht < 3 * T) { hr = ht - 2 * T; hc = -1; }
+        else if (ht < 4 * T) { hr = ht - 3 * T; hc = T; }
+        else { hr = (ht & 2) ? T : -1; hc = (ht & 1) ? T : -1; }
+        Gs[(hr + 1) * GP + hc + 1] = ring[ht];
+    }
+    for (int e = tid; e < CN; e += 256) {
+        const int cr = e / CROWS, cc = e - cr * CROWS, cx = x0 + cr - COFF, cy = y0 + cc - COFF, c = ct[e];
+        Cs[cr * CP + cc] = (cx < 0 || cy < 0 || cx >= P.L || cy >= P.W || c >= thr) ? INFINITY : (float)c;
+    }
+    __syncthreads();
+    const int goal_x = P.goal[2 * m], goal_y = P.goal[2 * m + 1];
+    for (int p = w; p < PT * PT; p += 4) {
+        const int lx = (p / PT) * 4 + (nd >> 2), ly = (p % PT) * 4 + (nd & 3);
+        QuadConsts<ALGO> C;
+        C.load(Cs, lx, ly, q);
+        const LaneEval le = eval_quad_w<ALGO>(Gs + (lx + 1) * GP + ly + 1, q, C);
+        const float nv = quad_min(le.r);
+        const int b = quad_min_int(bp_byte<ALGO>(le, q, C, le.r == nv));
+        if (q == 0) P.bp[(size_t)gt * TT + lx * T + ly] = (uint8_t)((x0 + lx == goal_x && y0 + ly == goal_y) ? BP_NONE : b);
+    }
+    __syncthreads();
+}
+template <int ALGO>
+__global__ __launch_bounds__(256) void k_finalize_bp(DevParams P, int only_if_done) {
+    __shared__ float Gs[(T + 2) * GP];
+    __shared__ float Cs[(T + 1) * CP];
+    if (only_if_done && !P.ctr->done) return;
+    const int n = P.ctr->tcount, thr = P.dyn->thr;
+    for (int i = blockIdx.x; i < n; i += gridDim.x) tile_bp<ALGO>(P, P.tlist[i], thr, Gs, Cs);
 }
 // Replan, end of the submission in one launch instead of three: every workgroup evaluates the
 // device-side end condition (the queues are short; workgroup 0 records the verdict), finalises its
@@ -2207,6 +2398,11 @@ struct Engine {
     GraphSig graph_sig{};
     std::vector<std::pair<int, hipGraphExec_t>> graphs;   // key nr * 256 + nl
     int relax_kernel(int mode, int k_arg, float rbound, int grid);
+    void finalize_bp(int only_if_done) {   // the back-pointers of the tiles the step touched (k_finalize_bp); MS-DFM level 0 has none (its map has no Info)
+        if (algo == UFM_ALGO_FD) k_finalize_bp<UFM_ALGO_FD><<<2048, 256, 0, stream>>>(P, only_if_done);
+        else if (algo == UFM_ALGO_SG) k_finalize_bp<UFM_ALGO_SG><<<2048, 256, 0, stream>>>(P, only_if_done);
+        else if (opt_lvl >= 1) k_finalize_bp<ALGO_DFM1><<<2048, 256, 0, stream>>>(P, only_if_done);
+    }
     int tail_grid = 96;              // replan graph: workgroups of the later launches of a phase (few tiles left)
     int replan_graph(int nr, int nl, float band, hipGraphExec_t *out);
     void drop_graphs() { for (auto &g : graphs) hipGraphExecDestroy(g.second); graphs.clear(); }
@@ -2285,7 +2481,7 @@ void Engine::release() {
     drop_graphs();                       // captured kernel arguments hold these pointers
     deferred.clear();
     std::memset(&graph_sig, 0, sizeof(graph_sig));
-    void *ptrs[] = {P.G, P.Gprev, P.ring, P.cost, P.costT, P.goal, P.cand, P.ready, P.hint, P.rank, P.park, P.pflag, P.pprio,
+    void *ptrs[] = {P.G, P.Gprev, P.bp, P.ring, P.cost, P.costT, P.goal, P.cand, P.ready, P.hint, P.rank, P.park, P.pflag, P.pprio,
                     P.queued, P.prio, P.start, P.bnd, P.dyn, P.spos, P.touched, P.fresh, P.tlist, P.sflag, P.slist, P.slist2,
                     P.mark, P.num_updated, P.consume, P.lmax, P.own_prio, P.own_lock, P.own_min, P.ctr, d_scratch};
     for (void *q : ptrs) if (q) hipFree(q);
@@ -2325,6 +2521,7 @@ int Engine::alloc(int width, int length) {
     };
     dmalloc(P.G, gbytes);
     dmalloc(P.Gprev, gbytes);
+    dmalloc(P.bp, P.gstride * nmaps);
     dmalloc(P.ring, (size_t)P.NT * RING * sizeof(float));
     dmalloc(P.cost, P.cstride * nmaps);
     dmalloc(P.costT, (size_t)P.NT * CTS);
@@ -2356,7 +2553,7 @@ int Engine::alloc(int width, int length) {
     dmalloc(P.own_lock, sizeof(int) * own_words());
     dmalloc(P.own_min, sizeof(int) * OWN_NW);
     dmalloc(P.ctr, sizeof(DevCounters));
-    dmalloc(d_scratch, sizeof(int) * (4 * nmaps + 4));
+    dmalloc(d_scratch, sizeof(int) * (4 * nmaps + 16));
     if (rc != UFM_OK) { release(); return rc; }
     rc = [&]() -> int {
         HIPCHK(hipMemsetAsync(P.rank, 0, sizeof(int) * P.NT, stream));
@@ -2373,6 +2570,7 @@ int Engine::alloc(int width, int length) {
         HIPCHK(hipMemsetAsync(P.goal, 0xFF, sizeof(int) * 2 * nmaps, stream));
         k_fill<<<1024, 256, 0, stream>>>(P.G, P.gstride * nmaps, INFINITY);
         k_fill<<<1024, 256, 0, stream>>>(P.Gprev, P.gstride * nmaps, INFINITY);
+        HIPCHK(hipMemsetAsync(P.bp, BP_NONE, P.gstride * nmaps, stream));
         k_fill<<<1024, 256, 0, stream>>>(P.ring, (size_t)P.NT * RING, INFINITY);
         dyn_dev = DevDyn{heur ? heuristic_multiplier : 0.0f, thr_uchar, focused ? 1 : 0, 0};
         k_set_dyn<<<1, 1, 0, stream>>>(P.dyn, dyn_dev);
@@ -2500,6 +2698,7 @@ int Engine::replan_graph(int nr, int nl, float band, hipGraphExec_t *out) {
     k_raise_to_lower<<<1, 1024, 0, stream>>>(P, -1);
     for (int i = 0; i < nl; ++i) relax_kernel(MODE_LOWER, -1 - i, INFINITY, std::min(grid_relax, grid_of(i)));
     k_replan_end<<<64, T * T, 0, stream>>>(P, -1 - nr, -1 - nl, band, h_ctr, h_flag, 0u);
+    finalize_bp(1);     // (behind the publication: the host does not wait for it, the next step's kernels do)
     hipGraph_t g = nullptr;
     HIPCHK(hipStreamEndCapture(stream, &g));
     hipGraphExec_t ge = nullptr;
@@ -2793,6 +2992,7 @@ int Engine::step(ufm_stats *out) {
             goals[2 * m] = ms.goal_elem_valid ? ms.goal_ex : -1;
             goals[2 * m + 1] = ms.goal_elem_valid ? ms.goal_ey : -1;
             k_fill<<<1024, 256, 0, stream>>>(P.G + (size_t)m * P.gstride, P.gstride, INFINITY);
+            HIPCHK(hipMemsetAsync(P.bp + (size_t)m * P.gstride, BP_NONE, P.gstride, stream));
             k_fill<<<256, 256, 0, stream>>>(P.ring + (size_t)m * P.NTm * RING, (size_t)P.NTm * RING, INFINITY);
             if (ms.goal_elem_valid) init_tiles[n_init++] = m * P.NTm + (ms.goal_ex / T) * P.TY + (ms.goal_ey / T);
             else ++n_init;   // nothing reachable: field stays +inf
@@ -3008,11 +3208,13 @@ int Engine::step(ufm_stats *out) {
         if (fused) {
             ++pub_seq;
             k_replan_end<<<64, T * T, 0, stream>>>(P, iter[Q_RAISE], iter[Q_LOWER], band, h_ctr, h_flag, pub_seq);
+            finalize_bp(1);
             HIPCHK(hipGetLastError());
             int rc = wait_published();
             if (rc != UFM_OK) return rc;
         } else {
             k_check<<<1, 1024, 0, stream>>>(P, iter[Q_RAISE], iter[Q_LOWER], band);
+            finalize_bp(1);
             k_finalize<<<2048, 256, 0, stream>>>(P, 1);
             HIPCHK(hipGetLastError());
             int rc = fetch_counters();
@@ -3143,6 +3345,7 @@ int Engine::step(ufm_stats *out) {
             if (!again) break;
         }
         const auto td = std::chrono::steady_clock::now();
+        finalize_bp(0);
         k_finalize<<<2048, 256, 0, stream>>>(P, 0);
         { int rc = fetch_counters(); if (rc != UFM_OK) return rc; }
         st.expanded = h_ctr->expanded;
@@ -3417,8 +3620,9 @@ int engine_extract_path(Engine *e, int max_steps, int lookahead, int allow_indir
     return UFM_OK;
 }
 
-// Back-pointers of a window of elements, derived from the field (k_info, ufm_path.h).
-int engine_read_info(Engine *e, int m, int x0, int y0, int nx, int ny, int32_t *info) {
+// Back-pointers of a window of elements: the stored codes in the reference's format (k_info_stored), or derived from the field alone
+// (k_info, the checker), ufm_path.h.
+int engine_read_info(Engine *e, int m, int x0, int y0, int nx, int ny, int32_t *info, bool derived) {
     if (!e || m < 0 || m >= e->nmaps || !e->allocated || !info) return UFM_ERR_INVALID;
     if (e->opt_lvl == 0) return UFM_ERR_INVALID;            // level 0: the map has no Info member (void)
     if (x0 < 0 || y0 < 0 || nx <= 0 || ny <= 0 || x0 + nx > e->P.EX || y0 + ny > e->P.EY) return UFM_ERR_INVALID;
@@ -3434,7 +3638,8 @@ int engine_read_info(Engine *e, int m, int x0, int y0, int nx, int ny, int32_t *
     F.G = e->P.G + (size_t)m * e->P.gstride; F.cost = e->P.cost + (size_t)m * e->P.cstride;
     F.EX = e->P.EX; F.EY = e->P.EY; F.L = e->P.L; F.W = e->P.W; F.TY = e->P.TY; F.thr = e->thr_uchar;
     F.cells = (e->algo == UFM_ALGO_DFM); F.indirect = (e->algo == UFM_ALGO_FD);   // FD: all five cost cases; SG: B / II / A
-    k_info<<<(unsigned)((n + 255) / 256), 256, 0, e->stream>>>(F, e->opt_lvl, x0, y0, nx, ny, d_out);
+    if (derived) k_info<<<(unsigned)((n + 255) / 256), 256, 0, e->stream>>>(F, e->opt_lvl, x0, y0, nx, ny, d_out);
+    else k_info_stored<<<(unsigned)((n + 255) / 256), 256, 0, e->stream>>>(F, e->P.bp + (size_t)m * e->P.gstride, x0, y0, nx, ny, d_out);
     hipError_t err = hipGetLastError();
     if (err == hipSuccess) err = hipMemcpyAsync(info, d_out, n * 2 * sizeof(int32_t), hipMemcpyDeviceToHost, e->stream);
     if (err == hipSuccess) err = hipStreamSynchronize(e->stream);
@@ -3568,6 +3773,35 @@ static int engine_check_layout(Engine *e, uint64_t *bad_ring, uint64_t *bad_cost
     return UFM_OK;
 }
 int ufm_check_layout(ufm_t *p, uint64_t *bad_ring, uint64_t *bad_cost) { return p ? engine_check_layout(p->e, bad_ring, bad_cost) : UFM_ERR_INVALID; }
+static int engine_check_info(Engine *e, uint64_t out[6]) {
+    if (!e || !e->allocated || !out) return UFM_ERR_INVALID;
+    if (e->algo == UFM_ALGO_DFM) return UFM_ERR_INVALID;       // (MS-DFM invalidates by evaluation: its bytes are for ufm_read_info only)
+    for (const MapState &ms : e->maps) if (!ms.have_map) return UFM_ERR_INVALID;
+    HIPCHK(hipSetDevice(e->device));
+    { int rc = e->flush_deferred(); if (rc != UFM_OK) return rc; }
+    unsigned long long *d_acc = reinterpret_cast<unsigned long long *>(e->d_scratch);
+    HIPCHK(hipMemsetAsync(d_acc, 0, 6 * sizeof(unsigned long long), e->stream));
+    if (e->algo == UFM_ALGO_SG) k_check_bp<UFM_ALGO_SG><<<1024, 256, 0, e->stream>>>(e->P, d_acc);
+    else k_check_bp<UFM_ALGO_FD><<<1024, 256, 0, e->stream>>>(e->P, d_acc);
+    unsigned long long h[6] = {0, 0, 0, 0, 0, 0};
+    HIPCHK(hipMemcpyAsync(h, d_acc, sizeof(h), hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    for (int i = 0; i < 6; ++i) out[i] = h[i];
+    return UFM_OK;
+}
+int ufm_check_info(ufm_t *p, uint64_t out[6]) { return p ? engine_check_info(p->e, out) : UFM_ERR_INVALID; }
+int ufm_batch_check_info(ufm_batch_t *b, uint64_t out[6]) {
+    if (!b || !out) return UFM_ERR_INVALID;
+    uint64_t acc[6] = {0, 0, 0, 0, 0, 0};
+    for (Engine *e : b->shards) {
+        uint64_t o[6];
+        const int rc = engine_check_info(e, o);
+        if (rc != UFM_OK) return rc;
+        for (int i = 0; i < 6; ++i) acc[i] += o[i];
+    }
+    for (int i = 0; i < 6; ++i) out[i] = acc[i];
+    return UFM_OK;
+}
 int ufm_batch_check_layout(ufm_batch_t *b, uint64_t *bad_ring, uint64_t *bad_cost) {
     if (!b) return UFM_ERR_INVALID;
     uint64_t r = 0, c = 0;
@@ -3744,7 +3978,8 @@ int ufm_batch_set_profiling(ufm_batch_t *b, int enable) {
 }
 void *ufm_batch_stream(ufm_batch_t *b, int shard) { return (b && shard >= 0 && shard < (int)b->shards.size()) ? (void *)b->shards[shard]->stream : nullptr; }
 
-int ufm_read_info(ufm_t *p, int x0, int y0, int nx, int ny, int32_t *info) { return p ? engine_read_info(p->e, 0, x0, y0, nx, ny, info) : UFM_ERR_INVALID; }
+int ufm_read_info(ufm_t *p, int x0, int y0, int nx, int ny, int32_t *info) { return p ? engine_read_info(p->e, 0, x0, y0, nx, ny, info, false) : UFM_ERR_INVALID; }
+int ufm_read_info_derived(ufm_t *p, int x0, int y0, int nx, int ny, int32_t *info) { return p ? engine_read_info(p->e, 0, x0, y0, nx, ny, info, true) : UFM_ERR_INVALID; }
 int ufm_extract_path(ufm_t *p, int max_steps, int lookahead, int allow_indirect,
                      float *path_xy, int cap_points, float *step_costs, int cap_costs, ufm_path_info *info) {
     return p ? engine_extract_path(p->e, max_steps, lookahead, allow_indirect, path_xy, cap_points, step_costs, cap_costs, info) : UFM_ERR_INVALID;

@@ -366,13 +366,14 @@ __global__ __launch_bounds__(64) void k_extract_path(PathField F0, size_t gstrid
     }
 }
 
-// ---- back-pointers (the reference's INFO member of a level-1/2 map element) as a view ----------
+// ---- back-pointers (the reference's INFO member of a level-1/2 map element) ----------------------
 // The reference stores, per expanded element, which neighbours its RHS came from
 // (FieldDPlanner_impl.h:86-111,196-208; ShiftedGridPlanner_impl.h:131-166,266-303;
-// DynamicFastMarching_impl.h:73-99,212-268) -- a device of its serial algorithm (which elements to
-// recompute when a neighbour is raised).  The engine does not need them (an element is invalidated
-// when its neighbours no longer reproduce its value), so they are not stored; this kernel derives
-// them on demand from the converged field, exactly as min_rhs<level>() would.
+// DynamicFastMarching_impl.h:73-99,212-268) and recomputes, when a neighbour is raised, only the elements
+// that point at it.  The engine stores one code per element (DevParams::bp, written with every value:
+// k_relax, ufm_region.h) and invalidates along it; k_info_stored turns the codes into the reference's
+// format.  k_info derives the same from the field alone, exactly as min_rhs<level>() would: the checker
+// of the stored ones (they may differ where two candidates tie).
 // Node planners: out[0] = linear index (x * EY + y) of the node b with RHS(s) = cost over the edge
 // (b, ccw_neighbor(s, b)), out[1] = -1.  DFM: the two cells of the winning stencil (-1: none,
 // -2: outside the grid).
@@ -418,6 +419,43 @@ __device__ float dfm_stencil(int ca, int cb, float ga, float gb, float tau, floa
     return ga + tau * h;
 }
 
+// The stored bytes ((code << 2) | dep, ufm_engine.hip; BP_NONE: the goal, or an element that never got a value -> -1, -1; likewise an
+// element whose value is +inf).  Node planners, code (q << 1) | h: the triangle of cell q -- (x-1+dx, y-1+dy), dx = q >> 1, dy = q & 1 -- over the vertical (h = 0) or the
+// horizontal (h = 1) neighbour p1 and the diagonal node p2 of that cell; b is the one of the two whose ccw_neighbor is the other.
+// MS-DFM level 1, code (q << 1) | w: the candidate of min_rhs_decreased_neighbor (impl:270-313) built on the neighbour w of axis q (vertical,
+// horizontal, TR-BL, TL-BR) and the better cell of the perpendicular pair; out = the pair compute_optimal_cost leaves (impl:322-342).
+__global__ void k_info_stored(PathField F, const uint8_t *bp, int x0, int y0, int nx, int ny, int32_t *out) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= nx * ny) return;
+    const int x = x0 + e / ny, y = y0 + e % ny;
+    int b0 = -1, b1 = -1;
+    const int code = bp[((size_t)(x / T) * F.TY + (y / T)) * (T * T) + (size_t)(x % T) * T + (y % T)];
+#ifdef UFM_BPDEBUG
+    if (code == 0xFD) { out[2 * e] = -3; out[2 * e + 1] = -3; return; }
+#endif
+    if (code != 0xFF && field_at(F, x, y) < INFINITY) {
+        const int q = (code >> 3) & 3, w = (code >> 2) & 1;      // the byte: (((q << 1) | w) << 2) | dep
+        if (F.cells) {
+            const int NX[4][2] = {{-1, 1}, {0, 0}, {-1, 1}, {-1, 1}}, NY[4][2] = {{0, 0}, {-1, 1}, {1, -1}, {-1, 1}};
+            // the perpendicular pair in the reference's argument order (best_cell: a tie goes to the second)
+            const int PAX[4] = {0, -1, -1, 1}, PAY[4] = {-1, 0, -1, -1}, PBX[4] = {0, 1, 1, -1}, PBY[4] = {1, 0, 1, 1};
+            const int qx = x + NX[q][w], qy = y + NY[q][w];
+            int px, py; float gp;
+            dfm_best(F, x + PAX[q], y + PAY[q], x + PBX[q], y + PBY[q], px, py, gp);
+            auto lin = [&](int ax, int ay) { return elem_ok(F, ax, ay) ? ax * F.EY + ay : -2; };
+            dfm_stencil(lin(qx, qy), lin(px, py), field_at(F, qx, qy), gp, raster_cost(F, x, y), q < 2 ? 1.0f : PATH_SQRT2, b0, b1);
+        } else {
+            const int dx = (q & 2) ? 1 : -1, dy = (q & 1) ? 1 : -1;
+            const int p1x = w ? x : x + dx, p1y = w ? y + dy : y, p2x = x + dx, p2y = y + dy;
+            int cx, cy;
+            ring_at(ring_of(p1x - x, p1y - y) + 1, cx, cy);
+            const bool p1_first = (x + cx == p2x) && (y + cy == p2y);
+            b0 = p1_first ? p1x * F.EY + p1y : p2x * F.EY + p2y;
+        }
+    }
+    out[2 * e] = b0;
+    out[2 * e + 1] = b1;
+}
 __global__ void k_info(PathField F, int lvl, int x0, int y0, int nx, int ny, int32_t *out) {
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= nx * ny) return;

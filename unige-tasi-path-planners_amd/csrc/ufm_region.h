@@ -21,10 +21,11 @@
 #ifndef UFM_REGION_IDLE_SLEEP
 #define UFM_REGION_IDLE_SLEEP 16          // an idle wave of the block kernel looks at its wake words this often (x 64 clocks): 1 / 4 / 16 / 32 / 64 -> 100 replans 18.9 / 18.0 / 17.6 / 17.6 / 17.8 ms (the looks of twelve idle waves take issue slots and LDS cycles from the four that sweep)
 #endif
-constexpr int RTMAX = 160 / T;            // block edge in tiles (10 for 16 x 16 tiles)
+constexpr int RTMAX = 128 / T;            // block edge in tiles (8 for 16 x 16 tiles: field 71 KB + cost bytes 17 KB + back-pointer codes 16 KB of the CU's 160 KB LDS)
 constexpr int RN = RTMAX * T;             // ... in elements (160)
 constexpr int RP = RN + 8;                // LDS pitch of the block's field: rows 4 apart on distinct banks (168 = 5*32 + 8)
 constexpr int RCP = RN + 4;               // pitch of the cost bytes
+constexpr int RBP = RN;                   // pitch of the back-pointer codes
 constexpr int TP = T / 4;                 // 4x4-element patches per tile side
 constexpr int RPW = RTMAX * TP / 4;       // patches per wave per side: patch (pr, pc) belongs to wave ((pr & 3) << 2 | (pc & 3))
 constexpr int RWW = (RPW * RPW + 31) / 32;   // wake words per wave
@@ -59,6 +60,9 @@ __device__ __forceinline__ int prio_read_fresh(const DevParams &P, int qz, int k
 struct RegionShared {
     int wake[16][RWW];                    // per wave: patches with new inputs
     int ever[16][RWW];                    // patches swept by the invalidation phase (they are re-lowered)
+    int renew[16][RWW];                   // patches whose back-pointers are renewed after the phases: those in which a value changed, and the patches around them
+    int tbp[RTMAX * RTMAX];               // tile holds renewed back-pointers (they are written back with the tile)
+    int seed[16][RWW];                    // node planners: patches holding elements of the consumed rectangles whose parent triangle has not been re-evaluated yet
     int defer[2][16][RWW];                // patches holding results beyond the bound (lower / raise)
     int dprio[2][RTMAX * RTMAX];          // per tile: smallest deferred priority (float bits)
     int tflag[RTMAX * RTMAX];             // tile has changed values
@@ -122,8 +126,9 @@ __device__ __forceinline__ float region_lower_bound(const float *Gs, const Regio
 
 // One phase (MODE_RAISE: invalidation, MODE_LOWER: lowering) of the block to quiescence.  All 16 waves call.
 template <int ALGO, int MODE>
-__device__ void region_phase(const DevParams &P, const RegionJob &J, float *Gs, const uint8_t *Cb, RegionShared &S,
+__device__ void region_phase(const DevParams &P, const RegionJob &J, float *Gs, const uint8_t *Cb, uint8_t *Bb, RegionShared &S,
                              int thr, float hm, int focused, int goal_lx, int goal_ly) {
+    constexpr bool BPRAISE = MODE == MODE_RAISE && !is_dfm<ALGO>;   // invalidation along the stored back-pointers (k_relax)
     const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
     const int q = lane & 3, nd = lane >> 2;
     const int nprow = J.ntx * TP, npcol = J.nty * TP;
@@ -162,6 +167,11 @@ __device__ void region_phase(const DevParams &P, const RegionJob &J, float *Gs, 
             bits = __builtin_amdgcn_readfirstlane(bits);
             if (!bits) continue;
             if (MODE == MODE_RAISE && lane == 0) S.ever[w][wd] |= bits;      // only this wave writes its own words
+            // Invalidation of the node planners follows the stored back-pointers: an element is gone when a vertex its value depends on is gone
+            // (the byte's dep bits: two LDS loads and a compare, no operator, no per-patch constants).  Only where cell costs changed -- the
+            // patches of the consumed rectangles, once -- is the parent triangle itself evaluated with the new costs (eval_quad_bp).
+            int seedbits = 0;
+            if (BPRAISE) seedbits = __builtin_amdgcn_readfirstlane(S.seed[w][wd]) & bits;
             while (bits) {
                 const int j = __ffs(bits) - 1;
                 if (budget <= 0) {                                           // out of budget: leave the rest for the queues
@@ -178,9 +188,16 @@ __device__ void region_phase(const DevParams &P, const RegionJob &J, float *Gs, 
                 const int pr = (idx / RPW) * 4 + (w >> 2), pc = (idx % RPW) * 4 + (w & 3);
                 if (pr >= nprow || pc >= npcol) continue;                    // (never woken; a block smaller than RTMAX)
                 const int lx = pr * 4 + (nd >> 2), ly = pc * 4 + (nd & 3);
+                const bool arith = BPRAISE && ((seedbits >> j) & 1);            // (wave-uniform)
                 QuadConsts<ALGO> C;
-                C.load_at(cost_at, lx, ly, q, RP);
+                if (!BPRAISE || arith) C.load_at(cost_at, lx, ly, q, RP);
                 float *ctr = Gs + (lx + 1) * RP + ly + 1;
+                uint8_t *bpp = Bb + lx * RBP + ly;
+                const int bpb = BPRAISE ? *bpp : BP_NONE;
+                // the two vertices of the element's parent triangle (LDS offsets) and whether its value depends on them
+                const int bqc = bpb >> 3, bsx = (bqc & 2) ? RP : -RP, bsy = (bqc & 1) ? 1 : -1;
+                const int bo1 = (bpb & 4) ? bsy : bsx, bo2 = bsx + bsy;
+                const bool bd1 = bpb & 1, bd2 = bpb & 2;
                 const bool goal = (lx == goal_lx) & (ly == goal_ly);
                 // wake targets: lane 0..8 = the 3x3 patches around this one (lane 4: itself)
                 int nwave = 0, nword = -1, nbit = 0;
@@ -213,11 +230,16 @@ __device__ void region_phase(const DevParams &P, const RegionJob &J, float *Gs, 
                 float g = ctr[0];
                 float dmin = INFINITY;                                        // smallest priority this lane deferred
                 float rmin_l = INFINITY;                                      // smallest value this lane invalidated
-                bool again = true;
+                bool again = true, pch = false;
                 int cnt = 0;
                 for (int b = 0; b < 16 && again; ++b) {
                     asm volatile("" ::: "memory");                          // re-read the block every sweep (other waves write it)
-                    float nv = quad_min(eval_quad<ALGO, RP>(ctr, q, C));
+                    float nv;
+                    if constexpr (BPRAISE) {
+                        if (arith && b == 0) nv = quad_min(eval_quad_bp<ALGO, RP>(ctr, q, C, bpb));
+                        else nv = ((bd1 & (ctr[bo1] == INFINITY)) | (bd2 & (ctr[bo2] == INFINITY))) ? INFINITY : g;
+                    }
+                    else nv = quad_min(eval_quad<ALGO, RP>(ctr, q, C));
                     if (goal) nv = 0.0f;
                     bool want, gate, doit;
                     if (MODE == MODE_LOWER) {
@@ -239,6 +261,7 @@ __device__ void region_phase(const DevParams &P, const RegionJob &J, float *Gs, 
                     const unsigned long long mask = __builtin_amdgcn_ballot_w64(gn != g);
                     const unsigned long long wanted = __builtin_amdgcn_ballot_w64(want & gate);   // lanes not yet settled (a colour-gated rise waits for its sweep)
                     g = gn;
+                    pch |= mask != 0ull;
                     UFM_SWEEP_FENCE();                                        // value before wake bit
                     if (mask != 0ull && lane == 0) S.tflag[tl] = 1;             // the tile holds changed values (write-back looks at these tiles only)
                     if ((mask & wake_sel) != 0ull && nword >= 0 && lane != 4)
@@ -247,6 +270,13 @@ __device__ void region_phase(const DevParams &P, const RegionJob &J, float *Gs, 
                     again = wanted != 0ull;
                 }
                 budget -= cnt; my_sweeps += cnt;
+                // (the patch and the eight around it: lanes 0..8 hold their wake words anyway)
+                if (pch && nword >= 0) __hip_atomic_fetch_or(&S.renew[nwave][nword], nbit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                // (a seeded patch that had to hold a result back is evaluated once more when it is woken again)
+                if (BPRAISE && arith) {
+                    const unsigned long long held = __builtin_amdgcn_ballot_w64(dmin < INFINITY);
+                    if (lane == 0 && held == 0ull) S.seed[w][wd] &= ~(1 << j);
+                }
                 if (MODE == MODE_RAISE && rmin_l < INFINITY && q == 0) { atomicMin(&S.rmin, __float_as_int(rmin_l)); S.traised[tl] = 1; }
                 if (dbg_count && lane == 0) { atomicAdd(&S.dbg[MODE == MODE_LOWER ? 5 : 4], 1); atomicAdd(&S.dbg[MODE == MODE_LOWER ? 7 : 6], cnt); }
                 if (again && lane == 0) __hip_atomic_fetch_or(&S.wake[w][wd], 1 << j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // burst cap
@@ -295,6 +325,7 @@ template <int ALGO>
 __global__ __launch_bounds__(NTHR) void k_replan_region(DevParams P, RegionJobs JS, DevCounters *host, unsigned int *flag) {
     __shared__ float Gs[(RN + 2) * RP];
     __shared__ uint8_t Cb[(RN + 1) * RCP];
+    __shared__ uint8_t Bb[RN * RBP];
     __shared__ RegionShared S;
     __shared__ int s_last;
     constexpr bool CELLS = is_dfm<ALGO>;
@@ -354,6 +385,7 @@ __global__ __launch_bounds__(NTHR) void k_replan_region(DevParams P, RegionJobs 
         const int tl = i / TT, e = i - tl * TT, ti = tl / J.nty, tj = tl - ti * J.nty;
         const int gt = gt0 + (J.tx0 + ti) * P.TY + J.ty0 + tj;
         Gs[(ti * T + e / T + 1) * RP + tj * T + e % T + 1] = P.G[(size_t)gt * TT + e];
+        Bb[(ti * T + e / T) * RBP + tj * T + e % T] = P.bp[(size_t)gt * TT + e];
     }
     for (int i = tid; i < 2 * (rny + 2) + 2 * rnx; i += NTHR) {
         int hx, hy;
@@ -385,6 +417,7 @@ __global__ __launch_bounds__(NTHR) void k_replan_region(DevParams P, RegionJobs 
             const int pr = p0 + i / (c1 - c0 + 1), pc = c0 + i % (c1 - c0 + 1);
             const int ni = (pr >> 2) * RPW + (pc >> 2);
             atomicOr(&S.wake[((pr & 3) << 2) | (pc & 3)][ni >> 5], 1 << (ni & 31));
+            atomicOr(&S.seed[((pr & 3) << 2) | (pc & 3)][ni >> 5], 1 << (ni & 31));
             S.traised[(pr / TP) * J.nty + pc / TP] = 1;      // a seeded tile is invalidated without a bound (the launch chain queues seeds with priority 0)
         }
     }
@@ -396,7 +429,7 @@ __global__ __launch_bounds__(NTHR) void k_replan_region(DevParams P, RegionJobs 
     // ---- 2. invalidate, lower; again while an invalidation that was held back lies below the start's new key ----
     for (int round = 0;; ++round) {
         for (;;) {
-            region_phase<ALGO, MODE_RAISE>(P, J, Gs, Cb, S, thr, hm, focused, goal_lx, goal_ly);
+            region_phase<ALGO, MODE_RAISE>(P, J, Gs, Cb, Bb, S, thr, hm, focused, goal_lx, goal_ly);
             // a tile that lost a value after some of its patches had been held back: those patches again
             const int again_t = __syncthreads_or(tid < ntl && S.traised[tid] && S.dprio[1][tid] != INFBITS) && !S.giveup;
             __syncthreads();
@@ -422,7 +455,7 @@ __global__ __launch_bounds__(NTHR) void k_replan_region(DevParams P, RegionJobs 
         }
         __syncthreads();
         for (int sub = 0;; ++sub) {
-            region_phase<ALGO, MODE_LOWER>(P, J, Gs, Cb, S, thr, hm, focused, goal_lx, goal_ly);
+            region_phase<ALGO, MODE_LOWER>(P, J, Gs, Cb, Bb, S, thr, hm, focused, goal_lx, goal_ly);
             // the start's key may have risen while results were being held back against an earlier value of it
             if (tid == 0) {
                 const float B = focused ? region_lower_bound(Gs, S) : INFINITY;
@@ -465,6 +498,33 @@ __global__ __launch_bounds__(NTHR) void k_replan_region(DevParams P, RegionJobs 
         __syncthreads();
     }
 
+    // ---- 2b. the back-pointers (what k_finalize_bp does for the launch chain's steps): every node of a patch in which a value changed, and of
+    // the patches around it -- a neighbour's value may be what it was and still come from another triangle now --, evaluated once more on the
+    // values as they stand, the arg-min kept.  (MS-DFM level 0 has none.)
+    if constexpr (ALGO != UFM_ALGO_DFM) {
+        const int w = tid >> 6, lane = tid & 63, q = lane & 3, nd = lane >> 2;
+        const int nprow = J.ntx * TP, npcol = J.nty * TP;
+        auto cost_at = [=](int r, int c) { const int b = Cb[r * RCP + c]; return b >= thr ? INFINITY : (float)b; };
+        for (int wd = 0; wd < RWW; ++wd) {
+            int bits = __builtin_amdgcn_readfirstlane(S.renew[w][wd]);
+            while (bits) {
+                const int j = __ffs(bits) - 1;
+                bits &= bits - 1;
+                const int idx = wd * 32 + j;
+                const int pr = (idx / RPW) * 4 + (w >> 2), pc = (idx % RPW) * 4 + (w & 3);
+                if (pr >= nprow || pc >= npcol) continue;
+                const int lx = pr * 4 + (nd >> 2), ly = pc * 4 + (nd & 3);
+                QuadConsts<ALGO> C;
+                C.load_at(cost_at, lx, ly, q, RP);
+                const LaneEval le = eval_quad_w<ALGO, RP>(Gs + (lx + 1) * RP + ly + 1, q, C);
+                const float nv = quad_min(le.r);
+                const int b = quad_min_int(bp_byte<ALGO>(le, q, C, le.r == nv));
+                if (q == 0) Bb[lx * RBP + ly] = (uint8_t)((lx == goal_lx && ly == goal_ly) ? BP_NONE : b);
+                if (lane == 0) S.tbp[(pr / TP) * J.nty + pc / TP] = 1;
+            }
+        }
+        __syncthreads();
+    }
     if (tid == 0) S.tstamp[4] = wall_clock64();
     // ---- 3. write back: changed values, the rings of the neighbours they border, what the frame has to hear ----
     // frame tile index of the tile at block coordinates (ti, tj), ti in -1..ntx, tj in -1..nty (one of them outside)
@@ -483,6 +543,10 @@ __global__ __launch_bounds__(NTHR) void k_replan_region(DevParams P, RegionJobs 
     for (int it = 0; it < PER; ++it) {
         const int i = tid + it * NTHR;
         init[it] = 0.0f;
+        if (i < ntl * TT && S.tbp[i / TT]) {      // the renewed back-pointers of the tile (a patch next to a changed one may lie in an unchanged tile)
+            const int tl = i / TT, e = i - tl * TT, ti = tl / J.nty, tj = tl - ti * J.nty;
+            P.bp[(size_t)(gt0 + (J.tx0 + ti) * P.TY + J.ty0 + tj) * TT + e] = Bb[(ti * T + e / T) * RBP + tj * T + e % T];
+        }
         if (i < ntl * TT && S.tflag[i / TT]) {
             const int tl = i / TT, ti = tl / J.nty, tj = tl - ti * J.nty;
             init[it] = P.G[(size_t)(gt0 + (J.tx0 + ti) * P.TY + J.ty0 + tj) * TT + (i - tl * TT)];
