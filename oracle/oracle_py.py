@@ -213,21 +213,27 @@ class OraclePlanner:
         self.L.orc_top_key(self.h, C.byref(a), C.byref(b))
         return a.value, b.value
 
-    def key1(self):
-        """first key component of every element for its current G: G (+ hm * dist(start, s))"""
-        g = self.g()
-        if not self.use_heuristic or self.start is None:
-            return g
-        nx, ny = g.shape
+    def _start_xy(self):
         sx, sy = self.start
         if self.algo == ALGO_DFM:
             sx, sy = float(_roundf(sx)), float(_roundf(sy))
-        xi, yi = np.meshgrid(np.arange(nx, dtype=np.float32), np.arange(ny, dtype=np.float32), indexing="ij")
-        return (g + np.float32(self.hm) * np.hypot(np.float32(sx) - xi, np.float32(sy) - yi).astype(np.float32)).astype(np.float32)
+        return sx, sy
+
+    def key1(self, window=None):
+        """first key component of every element (of the window (x0, x1, y0, y1)) for its current G: G (+ hm * dist(start, s))"""
+        g = self.g()
+        x0, x1, y0, y1 = window if window is not None else (0, g.shape[0], 0, g.shape[1])
+        g = g[x0:x1, y0:y1]
+        if not self.use_heuristic or self.start is None:
+            return g
+        sx, sy = self._start_xy()
+        dx = np.float32(sx) - np.arange(x0, x1, dtype=np.float32)
+        dy = np.float32(sy) - np.arange(y0, y1, dtype=np.float32)
+        return (g + np.float32(self.hm) * np.hypot(dx[:, None], dy[None, :]).astype(np.float32)).astype(np.float32)
 
     def start_key(self):
         """the reference's max_start_key (first component): over the start elements that are reached"""
-        g, rhs, k1 = self.g(), self.rhs(), self.key1()
+        g, rhs = self.g(), self.rhs()
         if self.start is None:
             return np.inf
         cx, cy = _roundf(self.start[0]), _roundf(self.start[1])
@@ -236,27 +242,27 @@ class OraclePlanner:
         for x, y in elems:
             if 0 <= x < g.shape[0] and 0 <= y < g.shape[1] and np.isfinite(rhs[x, y]):
                 # calculate_key uses min(g, rhs): a start corner may end with G = inf and a finite, final RHS
-                # (FieldDPlanner_impl.h:165-186, 225-256); k1 is built on G, so rebuild it on RHS there
-                k = k1[x, y] if g[x, y] <= rhs[x, y] else np.float32(k1[x, y] - g[x, y] + rhs[x, y]) if np.isfinite(g[x, y]) else None
-                if k is None:
-                    dist = 0.0
-                    if self.use_heuristic:
-                        sx, sy = self.start
-                        if self.algo == ALGO_DFM:
-                            sx, sy = float(_roundf(sx)), float(_roundf(sy))
-                        dist = float(np.hypot(np.float32(sx) - np.float32(x), np.float32(sy) - np.float32(y)))
-                    k = np.float32(rhs[x, y] + np.float32(self.hm) * np.float32(dist))
+                # (FieldDPlanner_impl.h:165-186, 225-256)
+                dist = np.float32(0.0)
+                if self.use_heuristic:
+                    sx, sy = self._start_xy()
+                    dist = np.float32(np.hypot(np.float32(sx) - np.float32(x), np.float32(sy) - np.float32(y)))
+                k = np.float32(min(g[x, y], rhs[x, y]) + np.float32(self.hm if self.use_heuristic else 0.0) * dist)
                 ks.append(k)
         return max(ks) if ks else np.inf
 
-    def trusted_mask(self, below_start_key=False):
+    def trusted_mask(self, below_start_key=False, window=None):
         """Elements whose value the reference guarantees final after step(): locally consistent
         (G==RHS<inf) and, D*-Lite invariant, with key not beyond the top of the queue.
         below_start_key additionally restricts to keys below the start's key -- the set a
-        planner that honours end_condition must have finalised."""
+        planner that honours end_condition must have finalised.  window = (x0, x1, y0, y1): the mask of that
+        part of the field only (the tests of the largest maps look at the neighbourhood of a replan)."""
         g, rhs = self.g(), self.rhs()
+        if window is not None:
+            x0, x1, y0, y1 = window
+            g, rhs = g[x0:x1, y0:y1], rhs[x0:x1, y0:y1]
         k1t, k2t = self.top_key()
-        k1 = self.key1()
+        k1 = self.key1(window)
         m = (g == rhs) & np.isfinite(g) & ((k1 < k1t) | ((k1 == k1t) & (g <= k2t if self.use_heuristic else True)))
         if below_start_key:
             m &= k1 < self.start_key()

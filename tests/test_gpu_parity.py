@@ -583,51 +583,135 @@ def test_config5_8192_heuristic_keys_moving_start_properties():
     g.close(); u.close()
 
 
+def test_config5_8192_heuristic_keys_moving_start_against_the_oracle():
+    """BASELINE.json config 5 against the oracle: Field D* level 1, 8192x8192, seed 42, heuristic keys (hm = the map's
+    smallest cost), the start moving with the patch script.  Plan + 8 replans.  After the plan and after the last replan
+    the WHOLE field is compared with the oracle on the set it guarantees final below the start's key -- bit for bit (FD),
+    layout and back-pointer self-checks included (check_parity); after every replan in between, the 1537 x 1537 nodes
+    around the start (a replan changes a few thousand nodes next to its patch; the whole-field mask of 67 M elements
+    costs the host more than the nine steps cost the oracle)."""
+    size, seed = 8192, 42
+    cost = ufm_amd.synth.cost_map(seed, size, size)
+    hm = float(cost.min())
+    start, goal = ufm_amd.synth.start_goal(size, size)
+    o, g = make_pair(ALGOS["FD"], 1, cost, start, goal, heuristic=True, hm=hm)
+    assert o.step() == 0 and g.step() == 0
+    n, nbad = check_parity(o, g, "config 5 plan", below_start_key=True)
+    assert nbad == 0 and n > 1_000_000
+    script = list(ufm_amd.synth.replan_script(seed, size, size, n_patches=8))
+    for k, s, top, left, patch in script:
+        for p in (o, g):
+            p.patch_map(patch, top, left)
+            p.set_heuristic_multiplier(hm)
+            p.set_start(*s)
+            assert p.step() == 0
+        assert g.num_nodes_updated == o.num_updated
+        x0, y0 = max(0, int(s[0]) - 768), max(0, int(s[1]) - 768)
+        x1, y1 = min(size + 1, x0 + 1537), min(size + 1, y0 + 1537)
+        mask = o.trusted_mask(below_start_key=True, window=(x0, x1, y0, y1))
+        assert int(mask.sum()) > 10_000
+        got = g.read_field(x0, y0, x1 - x0, y1 - y0)[0]
+        assert np.array_equal(got[mask], o.g()[x0:x1, y0:y1][mask]), "config 5 replan %d: field differs from the oracle around the start" % k
+        assert g.check_layout() == (0, 0) and g.check_info()[1:4] == (0, 0, 0)
+    n, nbad = check_parity(o, g, "config 5 after %d replans" % len(script), below_start_key=True)
+    assert nbad == 0 and n > 1_000_000
+    g.close()
+
+
+def test_batch_with_heuristic_keys_and_a_new_multiplier_every_round():
+    """A batch whose heuristic multiplier changes with every replan round (what the reference's harness does per
+    planner, Tests/Planners/DFM/main.cpp:111-112): every map's workgroup of the block kernel reads the per-step scalars
+    (the multiplier in start_bound / tile_heuristic) -- they are in device memory before the launch, not stored by one of
+    the workgroups during it.  Every map against its own oracle after every round, bit for bit."""
+    n, width, length = 5, 208, 176
+    b = ufm_amd.BatchPlanner(n, ufm_amd.ALGO_FD, 1, True)
+    b.set_occupancy_threshold(1.0)
+    b.set_heuristic_multiplier(1.0)
+    start, goal = (50.0, 40.0), (float(length - 8), float(width - 8))
+    oracles, costs = [], []
+    for m in range(n):
+        c = ufm_amd.synth.cost_map(300 + m, width, length)
+        costs.append(c)
+        b.set_map(m, c); b.set_start(m, *start); b.set_goal(m, *goal)
+        o = orc.OraclePlanner(orc.ALGO_FD, 1, True)
+        o.reset(); o.set_occupancy_threshold(1.0); o.set_heuristic_multiplier(1.0); o.set_map(c); o.set_start(*start); o.set_goal(*goal)
+        assert o.step() == 0
+        oracles.append(o)
+    assert b.step() == 0
+
+    def against(what):
+        for m, o in enumerate(oracles):
+            mask = o.trusted_mask(below_start_key=True)
+            assert int(mask.sum()) > 100
+            assert np.array_equal(b.read_field(m)[mask], o.g()[mask]), "%s: map %d differs from its oracle" % (what, m)
+        assert b.check_layout() == (0, 0)
+        assert b.check_info()[1:4] == (0, 0, 0), b.check_info()
+    against("plan")
+    regions0 = b.stats.region_replans
+    for k in range(1, 13):
+        hm = 1.0 - 0.03 * (k % 5)
+        b.set_heuristic_multiplier(hm)
+        s = (start[0] + 3 * k, start[1] + 2 * k)
+        for m, o in enumerate(oracles):
+            top, left = int(s[0]) - 15 + (m % 3), int(s[1]) - 15 + (m % 2)
+            patch = (1 + (ufm_amd.synth.h64((300 + m) ^ k, *np.meshgrid(np.arange(top, top + 31), np.arange(left, left + 31), indexing="ij")) % np.uint64(200))).astype(np.uint8)
+            b.patch_map(m, patch, top, left); b.set_start(m, *s)
+            o.patch_map(patch, top, left); o.set_heuristic_multiplier(hm); o.set_start(*s)
+            assert o.step() == 0
+        assert b.step() == 0
+        against("round %d hm %.2f" % (k, hm))
+    assert b.stats.region_replans > regions0      # the rounds did go through the block kernel (one workgroup per map)
+    b.close()
+
+
 def test_config4_batch_of_8_maps_2048_dfm():
-    """BASELINE.json config 4, one GPU's share: 8 independent 2048x2048 MS-DFM maps (seeds 1000..1007, SURVEY
-    8d) planned in one batch.  Two of the maps are compared with the oracle on the set it guarantees final and a
-    planner honouring end_condition must have finalised (helpers.DFM_RTOL) -- among them seed 1006, on which
-    block Gauss-Seidel between tiles used to cycle --, every map reaches its start, one launch extracts all eight
-    paths, and a replan round with a patch on every map is checked the same way."""
-    n, size = 8, 2048
+    """BASELINE.json config 4, one GPU's share: 8 independent 2048x2048 MS-DFM maps (seeds 1000..1007) in one
+    batch, every map with its own 100-patch stream -- the episode `bench.py --algo DFM --size 2048 --batch 8` times.
+    ALL eight maps against their oracles on the set the reference guarantees final below the start's key
+    (helpers.DFM_RTOL): after the plan, after every 10th replan round and after the last; all 100 rounds are stepped
+    (the oracles in lockstep).  Every map reaches its start, one launch extracts all eight paths."""
+    n, size, rounds = 8, 2048, 100
     b = ufm_amd.BatchPlanner(n, ufm_amd.ALGO_DFM, 1)
     b.set_occupancy_threshold(1.0)
     start, goal = ufm_amd.synth.start_goal(size, size)
-    costs = []
+    oracles, scripts = [], []
     for m in range(n):
         c = ufm_amd.synth.cost_map(1000 + m, size, size)
-        costs.append(c)
         b.set_map(m, c); b.set_start(m, *start); b.set_goal(m, *goal)
-    assert b.step() == 0
-    oracles = {}
-    for m in (3, 6):
         o = orc.OraclePlanner(orc.ALGO_DFM, 1, False)
-        o.reset(); o.set_occupancy_threshold(1.0); o.set_map(costs[m]); o.set_start(*start); o.set_goal(*goal)
+        o.reset(); o.set_occupancy_threshold(1.0); o.set_map(c); o.set_start(*start); o.set_goal(*goal)
         assert o.step() == 0
-        oracles[m] = o
+        oracles.append(o)
+        scripts.append(list(ufm_amd.synth.replan_script(1000 + m, size, size, n_patches=rounds)))
+    assert b.step() == 0
 
-    def against_oracle(what):
-        for m, o in oracles.items():
+    def against_oracle(what, least):
+        worst = 0.0
+        for m, o in enumerate(oracles):
             mask = o.trusted_mask(below_start_key=True)
-            assert int(mask.sum()) > 3_000_000
+            assert int(mask.sum()) > least
             a, ref = b.read_field(m)[mask], o.g()[mask]
             err = np.abs(a.astype(np.float64) - ref)
             assert np.all(err <= DFM_RTOL * ref), "%s map %d: max rel %.3g" % (what, m, float((err / ref.clip(1)).max()))
-    against_oracle("plan")
+            worst = max(worst, float((err / ref.clip(1)).max()))
+        return worst
+    against_oracle("plan", 3_000_000)
     for k in range(n):
         assert np.isfinite(b.read_field(k)[int(start[0]), int(start[1])])
     paths = b.extract_paths(max_steps=20)
     assert len(paths) == n and all(len(pt[0]) >= 2 and pt[2] > 0 for pt in paths)
-    # one replan round: every map gets its own 31x31 patch (map m: step m of its own script)
-    for m in range(n):
-        k, s, top, left, patch = list(ufm_amd.synth.replan_script(1000 + m, size, size, n_patches=m + 1))[m]
-        b.patch_map(m, patch, top, left); b.set_start(m, *s)
-        if m in oracles:
+    worst = 0.0
+    for i in range(rounds):
+        for m in range(n):
+            k, s, top, left, patch = scripts[m][i]
+            b.patch_map(m, patch, top, left); b.set_start(m, *s)
             oracles[m].patch_map(patch, top, left); oracles[m].set_start(*s)
             assert oracles[m].step() == 0
-    assert b.step() == 0
-    against_oracle("replan")
+        assert b.step() == 0
+        if (i + 1) % 10 == 0:
+            worst = max(worst, against_oracle("round %d" % (i + 1), 2_000_000))
     assert b.check_layout() == (0, 0)
+    print("config 4: 8 maps x 100 rounds, largest relative deviation from the oracle %.3g" % worst)
     b.close()
 
 

@@ -1,4 +1,4 @@
-"""Diagnostic (GPU box, -DUFM_TIMING build: UFM_LIB=build/libufm_timing.so): when does the resident plan kernel reach a tile, when does
+"""Diagnostic (GPU box, -DUFM_TIMING build, --lib build/exp/libufm_timing.so): when does the resident plan kernel reach a tile, when does
 the tile get its last change, and how long do its activations wait for the owner.  FD-1 full plan."""
 import argparse
 import ctypes as C
@@ -15,8 +15,10 @@ ap.add_argument("--size", type=int, default=4096)
 ap.add_argument("--seed", type=int, default=7)
 ap.add_argument("--param", action="append", default=[])
 ap.add_argument("--reps", type=int, default=2)
+ap.add_argument("--lib", default="build/exp/libufm_timing.so")
 ap.add_argument("--ys", type=int, default=4, help="log2 of the owner pattern's second edge: 4 (256 owners, 16 waves per visit) or 5 (512, 8 waves)")
 a = ap.parse_args()
+ufm_amd.use_library(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), a.lib))
 L = ufm_amd.load_library()
 L.ufm_debug_tiles.argtypes = [C.c_void_p, C.c_int]
 cost = ufm_amd.synth.cost_map(a.seed, a.size, a.size)

@@ -3144,7 +3144,10 @@ int Engine::step(ufm_stats *out) {
                 HIPCHK(hipMemsetAsync(&P.ctr->rbound, 0, offsetof(DevCounters, done_fail) + sizeof(int) - offsetof(DevCounters, rbound), stream));
                 k_fill<<<1, 64, 0, stream>>>(reinterpret_cast<float *>(&P.ctr->qmin[Q_RAISE]), (size_t)1, INFINITY);
             }
-            dyn_dev = dyn_now; dyn_pending = false;
+            // the per-step scalars: a single map's workgroup stores the job's copy itself (it is the only reader before the next launch); a batch's
+            // workgroups read *P.dyn side by side (start_bound, tile_heuristic), so there it is in place before the launch
+            if (rjs.j[0].batch) flush_dyn();
+            else { dyn_dev = dyn_now; dyn_pending = false; }
             const dim3 g(rjs.n), b(NTHR);
             if (algo == UFM_ALGO_FD) k_replan_region<UFM_ALGO_FD><<<g, b, 0, stream>>>(P, rjs, h_ctr, h_flag);
             else if (algo == UFM_ALGO_SG) k_replan_region<UFM_ALGO_SG><<<g, b, 0, stream>>>(P, rjs, h_ctr, h_flag);

@@ -338,7 +338,7 @@ __global__ __launch_bounds__(NTHR) void k_replan_region(DevParams P, RegionJobs 
 
     const unsigned long long t_begin = wall_clock64();
     // ---- 0. what k_replan_begin does: step bookkeeping, mark reset, the seeds, the invalidation bound ----
-    if (tid == 0 && blockIdx.x == 0) *P.dyn = J.dyn;
+    if (tid == 0 && !J.batch) *P.dyn = J.dyn;      // (a batch: the host has put them in place before the launch -- other workgroups read them too)
     if (!J.batch) step_begin(P, J.rb.sb);
     for (int r = 0; r < J.rb.nrect; ++r) {
         const int *qr = J.rb.rect[r];
