@@ -15,19 +15,20 @@ ranks by one RCCL broadcast per replan (the only exchange the path has).
   python bench.py --size 8192 --seed 42 --heuristic                          config 5 (this GPU's replica)
 
 `--gpus N` with N > 1 and no WORLD_SIZE in the environment: this process starts N rank processes (fresh
-interpreters, RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set) before anything touches a GPU, relays rank 0's
-line and exits with the first non-zero exit code.  Under `python -m torch.distributed.run` the ranks exist
-already and each process is one of them.
+interpreters, RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set) before anything touches a GPU, watches all of
+them -- the first one to fail ends the others within seconds, its stderr tail is relayed and its exit code is
+this process's; `--timeout` bounds the whole run --, relays rank 0's line.  Under
+`python -m torch.distributed.run` the ranks exist already and each process is one of them.
 
 Prints ONE JSON line on rank 0.
 """
 import argparse
-import importlib
 import json
 import os
 import socket
 import subprocess
 import sys
+import tempfile
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -77,11 +78,13 @@ def cpu_worker(spec):
     t0 = time.perf_counter()
     assert p.step() == 0
     exp += p.num_expanded; ms += p.u_time + p.p_time
+    plan_exp, plan_ms = exp, ms
     for k, s, top, left, patch in ufm_amd.synth.replan_script(seed, size, size, n_patches=spec["patches"]):
         p.patch_map(patch, top, left); p.set_start(*s)
         assert p.step() == 0
         exp += p.num_expanded; ms += p.u_time + p.p_time
-    print(json.dumps({"expanded": exp, "ms": ms, "wall_s": time.perf_counter() - t0}))
+    print(json.dumps({"expanded": exp, "ms": ms, "wall_s": time.perf_counter() - t0, "plan_ms": plan_ms, "plan_expanded": plan_exp,
+                      "replans_ms": ms - plan_ms, "replans_expanded": exp - plan_exp}))
 
 
 def cpu_baseline(size, seed, n_patches, algo_name, heuristic, n_maps):
@@ -104,7 +107,11 @@ def cpu_baseline(size, seed, n_patches, algo_name, heuristic, n_maps):
     else:               # a batch: all maps' expansions over the time the slowest process needed
         slow = max(r["ms"] for r in results) * 1e-3
         value, how = exp / slow, "%d expansions, slowest process %.1f s (wall incl. start-up %.1f s)" % (exp, slow, wall)
-    return {"value": value, "unit": "cells/s", "cores": used, "cores_used": used, "cores_host": cores_host, "kind": "port",
+    # the same split as the GPU line's "phases": the reference's own clocks (u_time + p_time) of the first step and of the replans,
+    # the slowest process of a batch
+    phases = {"plan_ms": max(r["plan_ms"] for r in results), "replans_ms": max(r["replans_ms"] for r in results),
+              "plan_cells": sum(r["plan_expanded"] for r in results), "replans_cells": sum(r["replans_expanded"] for r in results)}
+    return {"value": value, "unit": "cells/s", "cores": used, "cores_used": used, "cores_host": cores_host, "kind": "port", "phases": phases,
             "sample": "%s-%d%s %dx%d, %s, full plan + %d replans each: %s" % (
                 algo_name, opt_level(algo_name), " heuristic keys" if heuristic else "", size, size,
                 "seed %d" % seed if n_maps == 1 else "%d maps (seeds %d..%d), one pinned process per map on %d of %d host cores" % (
@@ -122,33 +129,79 @@ def free_port():
     return port
 
 
-def launch_ranks(n):
-    """Start n rank processes of this script (one per GPU) and relay rank 0's output.  Nothing in this process
-    has touched torch or the GPU."""
+def launch_ranks(n, script, argv, timeout_s):
+    """Start n rank processes of `script` (one per GPU) and watch ALL of them.  Nothing in this process has touched torch or the
+    GPU; the children are fresh interpreters.  Rank 0's stdout is collected (the one JSON line), every rank's stderr goes to a
+    file of its own.  The first rank that exits with a non-zero code -- or the timeout -- ends the others (terminate, then kill):
+    a rank that died before a collective must not leave the rest waiting in it until the backend's own timeout.  Returns that
+    code (124 for the timeout) after relaying the tail of the failing rank's stderr."""
     port = os.environ.get("MASTER_PORT") or str(free_port())
-    procs = []
+    logdir = tempfile.mkdtemp(prefix="bench_ranks_")
+    procs, errs = [], []
+    out0 = open(os.path.join(logdir, "rank0.out"), "w+")
     for r in range(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=port)
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
-                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=(r == 0)))
-    rc = 0
-    out0, _ = procs[0].communicate()
-    for r, pr in enumerate(procs):
-        code = pr.wait()
-        if code != 0 and rc == 0:
-            rc = code
-            print("bench.py: rank %d exited with code %d" % (r, code), file=sys.stderr)
-    for line in (out0 or "").splitlines():      # the contract is ONE JSON line on stdout; whatever else rank 0 printed goes to stderr
-        print(line, file=sys.stdout if line.startswith("{") else sys.stderr)
+        err = open(os.path.join(logdir, "bench_rank%d.err" % r), "w+")
+        errs.append(err)
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(script)] + list(argv), env=env,
+                                      stdout=out0 if r == 0 else subprocess.DEVNULL, stderr=err))
+    rc, failed = 0, None
+    deadline = time.monotonic() + timeout_s
+    live = set(range(n))
+    while live:
+        for r in sorted(live):
+            code = procs[r].poll()
+            if code is None:
+                continue
+            live.discard(r)
+            if code != 0 and rc == 0:
+                rc, failed = code, r
+        if rc != 0 or time.monotonic() > deadline:
+            break
+        time.sleep(0.05)
+    if live:                                         # a rank failed, or the timeout: end the others
+        if rc == 0:
+            rc, failed = 124, None
+        for r in live:
+            procs[r].terminate()
+        t_kill = time.monotonic() + 3.0
+        for r in live:
+            try:
+                procs[r].wait(timeout=max(0.1, t_kill - time.monotonic()))
+            except subprocess.TimeoutExpired:
+                procs[r].kill()
+                procs[r].wait()
+    out0.seek(0)
+    for line in out0.read().splitlines():      # the contract is ONE JSON line on stdout; whatever else rank 0 printed goes to stderr
+        print(line, file=sys.stdout if line.startswith("{") and rc == 0 else sys.stderr)
     sys.stdout.flush()
+    if rc != 0:
+        print("bench.py: %s; per-rank stderr in %s" % (
+            "rank %d exited with code %d, the other ranks were stopped" % (failed, rc) if failed is not None else "timeout after %.0f s" % timeout_s, logdir),
+            file=sys.stderr)
+        for r in ([failed] if failed is not None else range(n)):
+            errs[r].seek(0)
+            tail = errs[r].read().splitlines()[-40:]
+            print("---- rank %d stderr (tail) ----" % r, file=sys.stderr)
+            print("\n".join(tail), file=sys.stderr)
+    else:
+        for r in range(n):                     # warnings of a good run: rank by rank, not interleaved
+            errs[r].seek(0)
+            text = errs[r].read().strip()
+            if text:
+                print("---- rank %d stderr ----\n%s" % (r, text), file=sys.stderr)
+    for f in errs + [out0]:
+        f.close()
     return rc
 
 
 # ---------------------------------------------------------------------------------------------------------
 # one rank
 # ---------------------------------------------------------------------------------------------------------
-def run_rank(args):
+def run_rank(args, planner_factory=None, factory_label=None):
+    """planner_factory(kind, algo, lvl, heuristic, n_maps): a CPU stand-in planner instead of the HIP one -- the rehearsal of the
+    multi-rank control flow in tests/bench_rehearsal.py (there is no command-line way to get here)."""
     import torch
     import ufm_amd
     ep = ufm_amd.episode
@@ -156,13 +209,12 @@ def run_rank(args):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    rehearsal = args.planner_factory is not None          # CPU stand-in planner (tests of the multi-rank control flow)
+    rehearsal = planner_factory is not None
     if rehearsal:
-        mod, fn = args.planner_factory.split(":")
-        factory = getattr(importlib.import_module(mod), fn)
+        factory = planner_factory
         dev, dev_index = torch.device("cpu"), 0
         if args.backend == "nccl":
-            raise SystemExit("--planner-factory runs on the CPU: use --backend gloo")
+            raise SystemExit("a stand-in planner runs on the CPU: use --backend gloo")
     else:
         # one process per GPU; (a gloo rehearsal on a single-GPU box folds the ranks onto the devices there are)
         dev_index = local_rank % max(1, torch.cuda.device_count())
@@ -203,7 +255,9 @@ def run_rank(args):
         st = ufm_amd.capi.Stats.from_buffer_copy(snapshot)
         d = {"cells": st.expanded, "visits": st.tile_visits, "launches": st.launches, "kernel_ms": st.kernel_ms, "evals": st.elem_evals,
              "lower_visits": 0, "lower_launches": 0, "lower_kernel_ms": 0.0, "lower_timed": 0,
-             "res_visits": 0, "res_launches": 0, "res_kernel_ms": 0.0}
+             "res_visits": 0, "res_launches": 0, "res_kernel_ms": 0.0,
+             "reg_launches": st.region_launches, "reg_timed": st.region_timed, "reg_kernel_ms": st.region_kernel_ms, "reg_tiles": st.region_tiles,
+             "reg_cells": st.expanded if st.region_launches else 0}
         if st.resident_launches and st.resident_kernel_ms > 0:   # a plan: its lowering phase was one launch of the resident kernel
             d.update(res_visits=st.resident_tile_visits, res_launches=st.resident_launches, res_kernel_ms=st.resident_kernel_ms)
         timed = st.timed_launches - st.timed_raise_launches
@@ -274,7 +328,7 @@ def run_rank(args):
 
         def run_one():
             return ep.run_episode(planner, set_map=set_map, start=start, goal=goal, script=meta, stream=stream,
-                                  apply_patch=apply_patch, read_stats=step_stats)
+                                  apply_patch=apply_patch, read_stats=step_stats, phases=phases)
 
         def self_check():
             # every rank's raster must now be its own map with all the broadcast patches applied -- a collective
@@ -319,11 +373,23 @@ def run_rank(args):
             planner.set_param("profile_stride", 16)
             adopt_stream(planner.stream_ptr(0))
         stream = ep.RoundStream(rounds, d_recv, n_rounds, dist=dist, rank=rank, pipeline=not args.no_pipeline)
+        # The record headers (map id, top, left, edge: the planner surface takes positions as plain ints) are a recording like the
+        # patch bytes: rank 0 hands every rank a host copy of all rounds' headers ONCE, before the episodes -- reading them back
+        # from each received buffer was a device-to-host copy and a host synchronisation per replan round on every rank.  The bytes
+        # of a round still arrive by that round's broadcast; the engine reads them in stream order behind it.
+        if n_rounds:
+            if rank == 0:
+                hdr_all = torch.from_numpy(np.ascontiguousarray(rounds.cpu().numpy()[:, :, :ep.REC_HDR]).view(np.int32).reshape(n_rounds, n_global, 4).copy())
+            else:
+                hdr_all = torch.empty((n_rounds, n_global, 4), dtype=torch.int32)
+            if dist is not None:
+                hbuf = hdr_all if rehearsal or args.backend == "gloo" else hdr_all.to(dev)
+                dist.broadcast(hbuf, src=0)
+                hdr_all = hbuf.cpu()
+            hdr_all = hdr_all.numpy()
 
-        def headers_of(buf):
-            # the record headers on the host (the planner surface takes positions as plain ints); for a received
-            # buffer this is also the point where the host knows the broadcast has landed
-            return buf[:, :ep.REC_HDR].cpu().numpy().view(np.int32).reshape(-1, 4)
+        def headers_of(i, buf):
+            return hdr_all[i]
 
         def apply_record(b, m, buf, g, top, left, edge):
             if rehearsal:
@@ -339,7 +405,7 @@ def run_rank(args):
                     b.set_map_device(m, d_costs[m].data_ptr(), size, size)
 
         def run_one():
-            return ep.run_batch_episode(planner, M, first, set_maps, start, goal, starts, stream, headers_of, apply_record, step_stats)
+            return ep.run_batch_episode(planner, M, first, set_maps, start, goal, starts, stream, headers_of, apply_record, step_stats, phases=phases)
 
         def self_check():
             out = []
@@ -350,6 +416,8 @@ def run_rank(args):
                 out.append((m, planner.read_map(m, size, size), expect))
             return out
 
+    phases = {}         # host wall seconds of the episodes' parts, summed over warm-up and timed episodes (run_episode)
+
     def barrier():
         if not rehearsal:
             torch.cuda.synchronize()
@@ -358,9 +426,18 @@ def run_rank(args):
         if not rehearsal:
             torch.cuda.synchronize()
 
-    dt, per_step = ep.timed_episodes(run_one, args.steps, args.warmup, barrier)
+    def run_warm():     # (only the timed episodes count for the phase split)
+        r = run_one()
+        phases.clear()
+        return r
+    for _ in range(args.warmup):
+        run_warm()
+    dt, per_step = ep.timed_episodes(run_one, args.steps, 0, barrier)
+    last_snapshot = None
     if not rehearsal:       # the snapshots of every step of an episode -> one summed dict per episode
         summed = []
+        if per_step and per_step[-1]:
+            last_snapshot = per_step[-1][-1]
         for snaps in per_step:
             tot_ = {}
             for sn in snaps:
@@ -372,6 +449,7 @@ def run_rank(args):
     tot = [sum(d.get(k, 0) for d in per_step) for k in keys]
     low = [sum(d.get(k, 0) for d in per_step) for k in ("lower_visits", "lower_launches", "lower_kernel_ms", "lower_timed")]
     res = [sum(d.get(k, 0) for d in per_step) for k in ("res_visits", "res_launches", "res_kernel_ms")]
+    reg = [sum(d.get(k, 0) for d in per_step) for k in ("reg_launches", "reg_timed", "reg_kernel_ms", "reg_tiles", "reg_cells")]
 
     # self-check of the patch path (outside the timed region)
     for m, got, expect in self_check():
@@ -422,8 +500,16 @@ def run_rank(args):
                 "elem_evals_per_step_rank0": evals / max(1, args.steps),
             },
         }
+        # where the episode's time goes (rank 0's host clock around the calls, per timed episode): set_map (untimed by the metric's
+        # definition in the reference, inside the timed region here), the plan step, the replans (patch + set_start + step each)
+        steps_ = max(1, args.steps)
+        out["phases"] = {"set_map_ms": 1e3 * phases.get("set_map", 0.0) / steps_, "plan_ms": 1e3 * phases.get("plan", 0.0) / steps_,
+                         "replans_ms": 1e3 * phases.get("replans", 0.0) / steps_, "replans": n_rounds,
+                         "plan_cells": (cells - reg[4]) / steps_ if not rehearsal else None,
+                         "replans_cells": reg[4] / steps_ if not rehearsal else None,
+                         "note": "host wall per episode on rank 0; cells of the replans = those of the steps the block kernel ran (all of them here)"}
         if rehearsal:
-            out["rehearsal"] = "CPU stand-in planner %s over %s: control flow only, not a measurement" % (args.planner_factory, args.backend)
+            out["rehearsal"] = "CPU stand-in planner %s over %s: control flow only, not a measurement" % (factory_label, args.backend)
         lvis, llaunch, lkms, ltimed = low
         rvis, rlaunch, rkms = res
         traffic_ok = args.algo == "FD" and size == 4096 and M == 0 and not args.heuristic
@@ -470,6 +556,28 @@ def run_rank(args):
                 "kernel_time_share": avg_launch_s * llaunch / dt,
                 "note": "latency-bound (dependent in-LDS sweeps along the wavefront), not bandwidth-bound: see DESIGN.md",
             }
+        rl_, rt_, rk_, rtiles_, _rc = reg
+        if not rehearsal and rl_ > 0 and rt_ > 0 and rk_ > 0:
+            # the replans' kernel: k_replan_region, ONE workgroup per map runs a replan's invalidation and lowering on a block of tiles in
+            # LDS.  Units per SURVEY 8(d): the tiles it stages (block edge^2) x (9 B per element + halo); duration = HIP events attached
+            # to every 8th of its dispatches inside the timed region.
+            last = ufm_amd.capi.Stats.from_buffer_copy(last_snapshot) if last_snapshot is not None else None
+            avg_s = rk_ * 1e-3 / rt_
+            tiles_per = rtiles_ / rl_
+            ach = tiles_per * BYTES_PER_TILE_VISIT / avg_s / 1e9
+            rtraffic = None
+            tj = os.path.join(ROOT, "profiles", args.traffic_json)
+            if os.path.exists(tj) and traffic_ok:
+                rtraffic = json.load(open(tj)).get("region_traffic_bytes_per_launch")
+            out["roofline_replans"] = {
+                "bound": "hbm", "kernel": "k_replan_region<%s> (one launch per replan: invalidation + lowering of a block of tiles in one workgroup's LDS)" % args.algo,
+                "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": rtraffic,
+                "avg_launch_us": 1e6 * avg_s, "timed_launches": rt_, "launches": rl_, "tile_visits_per_launch": tiles_per,
+                "algorithmic_bytes_per_launch": tiles_per * BYTES_PER_TILE_VISIT,
+                "region_replans": last.region_replans if last else None, "region_replans_done": last.region_replans_done if last else None,
+                "kernel_time_share": avg_s * rl_ / dt,
+                "note": "one CU of 256: a replan changes ~1 k elements; latency-bound chain of dependent patch sweeps (DESIGN.md 4.6)",
+            }
         if not rehearsal and not args.no_cpu_baseline and world == 1:   # the CPU baseline is reported at N = 1 only
             out["cpu_baseline"] = cpu_baseline(args.cpu_size, seed, n_rounds, args.algo, bool(args.heuristic), n_local)
         print(json.dumps(out))
@@ -479,9 +587,12 @@ def run_rank(args):
         dist.destroy_process_group()
 
 
-def main():
-    if len(sys.argv) >= 3 and sys.argv[1] == "--cpu-worker":
-        cpu_worker(json.loads(sys.argv[2]))
+def main(argv=None, planner_factory=None, factory_label=None, script=None):
+    """argv: the command line (default sys.argv[1:]); planner_factory / factory_label / script: the CPU rehearsal of
+    tests/bench_rehearsal.py (a stand-in planner, and the file the rank processes are started from)."""
+    argv = list(sys.argv[1:] if argv is None else argv)
+    if len(argv) >= 2 and argv[0] == "--cpu-worker":
+        cpu_worker(json.loads(argv[1]))
         return 0
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -505,13 +616,11 @@ def main():
                     help="broadcast each patch right before its replan instead of one replan ahead")
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise the process group and run the collectives even with one rank (rehearses the RCCL path on a one-GPU box)")
-    ap.add_argument("--planner-factory", default=None, metavar="MODULE:FUNCTION",
-                    help="test hook: run the episode on a CPU stand-in planner made by MODULE.FUNCTION(kind, algo, lvl, heuristic, n_maps) "
-                         "(control flow of the launcher / collectives without a GPU; the line is marked as a rehearsal)")
+    ap.add_argument("--timeout", type=float, default=1500.0, help="--gpus N self-launch: seconds after which the rank processes are stopped (exit code 124)")
     ap.add_argument("--param", action="append", default=[], metavar="NAME=VALUE",
                     help="scheduler knob for the engine (ufm_set_param / ufm_batch_set_param), e.g. owned_waves=16; for experiments -- the defaults are the product")
-    ap.add_argument("--traffic-json", default="r2_traffic.json", help="file under profiles/ holding the separately collected PMC traffic of the headline run")
-    args = ap.parse_args()
+    ap.add_argument("--traffic-json", default="r3_traffic.json", help="file under profiles/ holding the separately collected PMC traffic of the headline run")
+    args = ap.parse_args(argv)
     if args.seed is None:
         args.seed = 1000 if args.batch > 0 else 7
     if args.cpu_size is None:
@@ -520,10 +629,10 @@ def main():
         raise SystemExit("--gpus >= 1, --batch >= 0")
     env_world = os.environ.get("WORLD_SIZE")
     if args.gpus > 1 and env_world is None:
-        return launch_ranks(args.gpus)                 # nothing above has imported torch or touched a GPU
+        return launch_ranks(args.gpus, script or __file__, argv, args.timeout)      # nothing above has imported torch or touched a GPU
     if env_world is not None and int(env_world) != args.gpus and int(env_world) > 1:
         print("bench.py: --gpus %d but WORLD_SIZE=%s; the process group decides" % (args.gpus, env_world), file=sys.stderr)
-    run_rank(args)
+    run_rank(args, planner_factory, factory_label)
     return 0
 
 

@@ -67,6 +67,10 @@ typedef struct ufm_stats {
     float resident_kernel_ms;      /*   its duration (HIP events attached to the dispatch); 0 unless profiling is on */
     uint32_t resident_stops;       /*   cumulative: workgroups that left it on its time limit instead of on an empty queue (expected: 0) */
     uint64_t resident_tile_visits; /*   tile visits it made (part of tile_visits) */
+    uint32_t region_launches;      /* replans: launches of the block-resident kernel in this step (0 or 1; one workgroup per map of a batch) */
+    uint32_t region_timed;         /*   ... of which timed (profiling: every 8th, the event packets are not free) */
+    float region_kernel_ms;        /*   duration of the timed launch (HIP events attached to the dispatch) */
+    uint32_t region_tiles;         /*   tiles it staged (block edge^2 per map): its tile visits for the algorithmic-bytes accounting */
 } ufm_stats;
 
 /* ---- lifetime: `PlannerT<OPT_LVL> planner{}` (e.g. Tests/Planners/FDSTAR/main.cpp:77) ---- */

@@ -1,4 +1,4 @@
-"""CPU stand-in planners for `bench.py --planner-factory rehearsal_planner:make` (tests only): the oracle behind
+"""CPU stand-in planners for tests/bench_rehearsal.py (tests only): the oracle behind
 the Python surface of ufm_amd.Planner / ufm_amd.BatchPlanner, so that the launcher, the process group, the
 broadcasts and the reductions of bench.py can run end to end without a GPU."""
 import numpy as np

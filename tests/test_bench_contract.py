@@ -38,6 +38,15 @@ def test_bench_line_single_gpu():
     assert "traffic_source" in r                      # the PMC traffic is a separately collected number and says so
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] == 1 and c["cores_used"] == 1 and c["cores_host"] >= 1 and c["value"] > 0 and "sample" in c
+    # the split that settles "GPU against one core" for the plan and for the replans from the line alone
+    ph, cph = d["phases"], c["phases"]
+    assert ph["plan_ms"] > 0 and ph["replans_ms"] > 0 and ph["set_map_ms"] > 0 and ph["replans"] == 6
+    assert abs(ph["plan_ms"] + ph["replans_ms"] + ph["set_map_ms"] - d["ms_per_step"]) < 0.05 * d["ms_per_step"] + 0.2
+    assert ph["plan_cells"] > 0 and ph["replans_cells"] > 0 and cph["plan_ms"] > 0 and cph["replans_ms"] > 0
+    # ... and the replans' kernel has a roofline entry of its own
+    rr = d["roofline_replans"]
+    assert rr["bound"] == "hbm" and rr["launches"] == 6 and rr["timed_launches"] >= 1 and rr["avg_launch_us"] > 0
+    assert abs(rr["frac"] - rr["achieved"] / rr["peak"]) < 1e-12 and rr["region_replans"] >= rr["region_replans_done"] > 0
 
 
 def test_bench_line_with_collectives_one_rank():

@@ -1,11 +1,13 @@
 """CPU: `bench.py --gpus 2` starts its two ranks itself (no torchrun), forms a gloo process group, broadcasts
 every patch / every replan round from rank 0 and prints ONE line with n_gpus == 2.  The planner is the oracle
-behind bench.py's --planner-factory hook (tests/rehearsal_planner.py); the same code path runs the HIP planner
-on RCCL on the GPU boxes."""
+behind the Python planner surface (tests/rehearsal_planner.py), handed to bench.main() by tests/bench_rehearsal.py
+-- the shipped benchmark has no import hook --; the same code path runs the HIP planner on RCCL on the GPU boxes.
+A rank that fails ends the run within seconds, with its exit code and its traceback."""
 import json
 import os
 import subprocess
 import sys
+import time
 
 import numpy as np
 
@@ -18,7 +20,7 @@ def _bench(*extra, env_extra=None):
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
     env["PYTHONPATH"] = os.pathsep.join([os.path.join(ROOT, "tests"), os.path.join(ROOT, "oracle"), env.get("PYTHONPATH", "")])
     env.update(env_extra or {})
-    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--backend", "gloo", "--planner-factory", "rehearsal_planner:make",
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "bench_rehearsal.py"), "--backend", "gloo",
                           "--steps", "1", "--warmup", "1", *extra], capture_output=True, text=True, timeout=600, env=env)
     assert out.returncode == 0, out.stderr[-3000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
@@ -60,6 +62,30 @@ def test_self_launcher_two_ranks_batch_with_per_map_patch_streams():
     # map g (global id) has the map AND the patch stream of seed 1000 + g
     expect = sum(_oracle_cells("DFM", 1, 1000 + g, 1000 + g, size, patches) for g in range(2 * M))
     assert abs(d["value"] * d["ms_per_step"] * 1e-3 - expect) < 1e-6 * expect
+
+
+def test_a_failing_rank_ends_the_run_with_its_code_and_traceback():
+    """Rank 1's planner cannot be made: it dies before the first collective.  The launcher must not sit in rank 0's
+    communicate() while rank 0 waits in a broadcast for the backend's timeout (up to 30 min with gloo): it stops the
+    other rank and exits non-zero within seconds, with rank 1's traceback on stderr."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    t0 = time.time()
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "bench_rehearsal.py"), "--backend", "gloo", "--steps", "1", "--warmup", "0",
+                          "--gpus", "2", "--size", "64", "--patches", "2", "--fail-rank", "1"], capture_output=True, text=True, timeout=120, env=env)
+    dt = time.time() - t0
+    assert out.returncode != 0
+    assert dt < 20.0, "the launcher took %.1f s to notice the dead rank" % dt
+    assert "rank 1 exited with code" in out.stderr and "fails on purpose" in out.stderr, out.stderr[-2000:]
+    assert not [l for l in out.stdout.splitlines() if l.startswith("{")]      # no result line from a failed run
+
+
+def test_the_launcher_timeout_stops_the_ranks():
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    t0 = time.time()
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "bench_rehearsal.py"), "--backend", "gloo", "--steps", "50", "--warmup", "0",
+                          "--gpus", "2", "--size", "512", "--patches", "100", "--timeout", "3"], capture_output=True, text=True, timeout=120, env=env)
+    assert out.returncode == 124 and time.time() - t0 < 30.0
+    assert "timeout after 3 s" in out.stderr
 
 
 def test_one_rank_needs_no_process_group():

@@ -52,6 +52,10 @@ class Stats(C.Structure):
         ("resident_kernel_ms", C.c_float),
         ("resident_stops", C.c_uint32),
         ("resident_tile_visits", C.c_uint64),
+        ("region_launches", C.c_uint32),
+        ("region_timed", C.c_uint32),
+        ("region_kernel_ms", C.c_float),
+        ("region_tiles", C.c_uint32),
     ]
 
     def as_dict(self):

@@ -2379,6 +2379,7 @@ struct Engine {
                                      //     here, and a workgroup that finds nothing inside the band idles: wider pays)
     uint32_t owned_launches = 0;
     hipEvent_t own_ev[2] = {nullptr, nullptr};
+    hipEvent_t reg_ev[2] = {nullptr, nullptr};     // profiling: around the block kernel of a replan
     bool own_timed = false;
     int owned_flags = 0;             // resident kernel, diagnostics and variants.  1: no tile taken ahead; 2: no early hand-off (FD / SG); 4: early hand-off once per patch and visit;
                                      // 8: early hand-off waits for its stores inside the sweep loop; 16: no in-visit halo refresh; 32: idle workgroups do not help out
@@ -3149,14 +3150,28 @@ int Engine::step(ufm_stats *out) {
             if (rjs.j[0].batch) flush_dyn();
             else { dyn_dev = dyn_now; dyn_pending = false; }
             const dim3 g(rjs.n), b(NTHR);
-            if (algo == UFM_ALGO_FD) k_replan_region<UFM_ALGO_FD><<<g, b, 0, stream>>>(P, rjs, h_ctr, h_flag);
-            else if (algo == UFM_ALGO_SG) k_replan_region<UFM_ALGO_SG><<<g, b, 0, stream>>>(P, rjs, h_ctr, h_flag);
-            else if (opt_lvl == 0) k_replan_region<UFM_ALGO_DFM><<<g, b, 0, stream>>>(P, rjs, h_ctr, h_flag);
-            else k_replan_region<ALGO_DFM1><<<g, b, 0, stream>>>(P, rjs, h_ctr, h_flag);
+            const bool reg_timed = profiling && (region_runs & 7u) == 0u;     // a sample: the event packets cost a few microseconds each
+            if (reg_timed) for (auto &e : reg_ev) if (!e) HIPCHK(hipEventCreate(&e));
+#define UFM_LAUNCH(A) do { if (reg_timed) hipExtLaunchKernelGGL((k_replan_region<A>), g, b, 0, stream, reg_ev[0], reg_ev[1], 0, P, rjs, h_ctr, h_flag); \
+                           else k_replan_region<A><<<g, b, 0, stream>>>(P, rjs, h_ctr, h_flag); } while (0)
+            if (algo == UFM_ALGO_FD) UFM_LAUNCH(UFM_ALGO_FD);
+            else if (algo == UFM_ALGO_SG) UFM_LAUNCH(UFM_ALGO_SG);
+            else if (opt_lvl == 0) UFM_LAUNCH(UFM_ALGO_DFM);
+            else UFM_LAUNCH(ALGO_DFM1);
+#undef UFM_LAUNCH
             HIPCHK(hipGetLastError());
             last_active = 1;
             int rc = wait_published();
             if (rc != UFM_OK) return rc;
+            st.region_launches = 1u;
+            for (int i = 0; i < rjs.n; ++i) st.region_tiles += (uint32_t)(rjs.j[i].ntx * rjs.j[i].nty);
+            if (reg_timed) {      // (the kernel has published its result: its stop event follows within microseconds -- spin, do not sleep)
+                hipError_t q;
+                while ((q = hipEventQuery(reg_ev[1])) == hipErrorNotReady) __builtin_ia32_pause();
+                HIPCHK(q);
+                HIPCHK(hipEventElapsedTime(&st.region_kernel_ms, reg_ev[0], reg_ev[1]));
+                st.region_timed = 1u;
+            }
             region_runs += (uint32_t)rjs.n;
             if (h_ctr->done) region_done += (uint32_t)rjs.n;
             else if (focused) {
@@ -3461,6 +3476,7 @@ int engine_destroy(Engine *e) {
     e->release();
     for (hipEvent_t v : e->ev) hipEventDestroy(v);
     for (hipEvent_t v : e->own_ev) if (v) hipEventDestroy(v);
+    for (hipEvent_t v : e->reg_ev) if (v) hipEventDestroy(v);
     if (e->d_patch) hipFree(e->d_patch);
     if (e->d_pmask) hipFree(e->d_pmask);
     if (e->d_field) hipFree(e->d_field);
@@ -3967,6 +3983,7 @@ int ufm_batch_step(ufm_batch_t *b, ufm_stats *stats) {
             a.region_replans += c.region_replans; a.region_replans_done += c.region_replans_done;
             a.resident_launches += c.resident_launches; a.resident_kernel_ms += c.resident_kernel_ms;
             a.resident_stops += c.resident_stops; a.resident_tile_visits += c.resident_tile_visits;
+            a.region_launches += c.region_launches; a.region_timed += c.region_timed; a.region_kernel_ms += c.region_kernel_ms; a.region_tiles += c.region_tiles;
         }
         *stats = a;
     }

@@ -66,12 +66,14 @@ class PatchStream:
         return buf
 
 
-def run_episode(planner, set_map, start, goal, script, stream, apply_patch, read_stats):
+def run_episode(planner, set_map, start, goal, script, stream, apply_patch, read_stats, phases=None):
     """script: list of (k, start_xy, top, left).  Returns the summed statistics dict -- or, when read_stats hands out opaque
     per-step snapshots instead of dicts (bench.py: a byte copy of the statistics struct, half a microsecond instead of the ten a
-    dict of thirteen ctypes fields costs per replan), the list of them, for the caller to evaluate outside its timed region."""
+    dict of thirteen ctypes fields costs per replan), the list of them, for the caller to evaluate outside its timed region.
+    phases (a dict): host wall seconds of the episode's parts are added to its "set_map", "plan" and "replans" entries."""
     tot = {}
     raw = []
+    t0 = time.perf_counter()
 
     def acc():
         r = read_stats(planner)
@@ -82,6 +84,7 @@ def run_episode(planner, set_map, start, goal, script, stream, apply_patch, read
             raw.append(r)
 
     set_map(planner)
+    t1 = time.perf_counter()
     planner.reset()
     planner.set_start(*start)
     planner.set_goal(*goal)
@@ -89,6 +92,7 @@ def run_episode(planner, set_map, start, goal, script, stream, apply_patch, read
     if rc != 0:
         raise RuntimeError("plan step failed: %d" % rc)
     acc()
+    t2 = time.perf_counter()
     for i, (k, s, top, left) in enumerate(script):
         apply_patch(planner, stream.fetch(i), top, left)
         planner.set_start(*s)
@@ -96,6 +100,10 @@ def run_episode(planner, set_map, start, goal, script, stream, apply_patch, read
         if rc != 0:
             raise RuntimeError("replan %d failed: %d" % (k, rc))
         acc()
+    if phases is not None:
+        t3 = time.perf_counter()
+        for key, dt in (("set_map", t1 - t0), ("plan", t2 - t1), ("replans", t3 - t2)):
+            phases[key] = phases.get(key, 0.0) + dt
     return raw if raw else tot
 
 
@@ -172,12 +180,13 @@ class RoundStream:
         return buf
 
 
-def run_batch_episode(batch, n_maps, first_map, set_maps, start, goal, starts, stream, headers_of, apply_record, read_stats):
+def run_batch_episode(batch, n_maps, first_map, set_maps, start, goal, starts, stream, headers_of, apply_record, read_stats, phases=None):
     """Full plan of the rank's n_maps maps (global ids first_map ..), then one batch step per replan round.
-    starts[i]: the start position of round i; headers_of(buf) -> int32 ndarray [n_global][4] (host copy of the
-    record headers); apply_record(batch, local_map, buf, global_map, top, left, edge)."""
+    starts[i]: the start position of round i; headers_of(i, buf) -> int32 ndarray [n_global][4] (the record headers of
+    round i on the host); apply_record(batch, local_map, buf, global_map, top, left, edge); phases: as run_episode."""
     tot = {}
     raw = []
+    t0 = time.perf_counter()
 
     def acc():           # (dicts are summed here, opaque snapshots handed back: see run_episode)
         r = read_stats(batch)
@@ -188,6 +197,7 @@ def run_batch_episode(batch, n_maps, first_map, set_maps, start, goal, starts, s
             raw.append(r)
 
     set_maps(batch)
+    t1 = time.perf_counter()
     for m in range(n_maps):
         batch.reset(m)
         batch.set_start(m, *start)
@@ -196,9 +206,10 @@ def run_batch_episode(batch, n_maps, first_map, set_maps, start, goal, starts, s
     if rc != 0:
         raise RuntimeError("batch plan step failed: %d" % rc)
     acc()
+    t2 = time.perf_counter()
     for i in range(stream.count):
         buf = stream.fetch(i)
-        hdr = headers_of(buf)
+        hdr = headers_of(i, buf)
         for m in range(n_maps):
             g, top, left, edge = (int(v) for v in hdr[first_map + m])
             if g != first_map + m:
@@ -209,4 +220,8 @@ def run_batch_episode(batch, n_maps, first_map, set_maps, start, goal, starts, s
         if rc != 0:
             raise RuntimeError("batch replan round %d failed: %d" % (i, rc))
         acc()
+    if phases is not None:
+        t3 = time.perf_counter()
+        for key, dt in (("set_map", t1 - t0), ("plan", t2 - t1), ("replans", t3 - t2)):
+            phases[key] = phases.get(key, 0.0) + dt
     return raw if raw else tot
