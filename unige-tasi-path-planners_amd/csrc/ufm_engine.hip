@@ -348,9 +348,21 @@ __device__ unsigned long long g_push64[TILE_DIAG_MAX];     // per tile: {time, s
 __device__ unsigned int g_vis[VIS_DIAG_MAX][5];
 __device__ unsigned int g_nvis;
 #endif
+// -DUFM_STRICT_FENCES (a checking build, libufm_strict.so: tests/test_strict_fences.py holds the product build to it bit for bit): the
+// textbook form of the protocol -- an agent-scope release fence in front of every activation and of every lock release, an agent-scope
+// acquire fence behind every take -- next to the product's argued one (sc1 stores and loads, s_waitcnt vmcnt(0), relaxed atomics; the table
+// in DESIGN.md section 4.7).  A release here writes the XCD's L2 back, an acquire invalidates it: several times slower, same results.
+#ifdef UFM_STRICT_FENCES
+#define UFM_STRICT_RELEASE() __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent")
+#define UFM_STRICT_ACQUIRE() __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent")
+#else
+#define UFM_STRICT_RELEASE()
+#define UFM_STRICT_ACQUIRE()
+#endif
 __device__ __forceinline__ void own_push(const DevParams &P, int gt, int pbits, int from = -1) {
     int o, s;
     own_locate(P, gt, o, s);
+    UFM_STRICT_RELEASE();
     __hip_atomic_fetch_min(&P.own_prio[(size_t)o * P.own_slots + s], pbits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __hip_atomic_fetch_min(&P.own_min[o], pbits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #ifdef UFM_TIMING
@@ -1066,6 +1078,7 @@ __global__ __launch_bounds__(OWNK == 2 ? NTHR / 2 : NTHR, UFM_RELAX_WAVES) void 
             own_slot_now = own_next;
             own_next = -1;
             __syncthreads();                                   // LDS of the previous visit is free
+            UFM_STRICT_ACQUIRE();                              // (checking build: the take is behind us, the staging loads in front)
         }
         if (DYN && !first_pop) {                           // next ready tile, whoever is free takes it
             __syncthreads();
@@ -1404,6 +1417,7 @@ __global__ __launch_bounds__(OWNK == 2 ? NTHR / 2 : NTHR, UFM_RELAX_WAVES) void 
             if (lane == 0) was = __hip_atomic_exchange(&P.own_prio[own_slot_now], OWN_MARK + (int)blockIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             was = __builtin_amdgcn_readfirstlane(was);
+            UFM_STRICT_ACQUIRE();
             if (was < INFBITS) {                 // (an activation: its values were stored before it was queued)
                 if (lane == 0) atomicMin(&s_emin[w * 9 + 4], was);   // (its priority counts for the tile's own, should the visit end at the sweep cap)
                 int t_ = tid;
@@ -1649,7 +1663,7 @@ __global__ __launch_bounds__(OWNK == 2 ? NTHR / 2 : NTHR, UFM_RELAX_WAVES) void 
         }
         __syncthreads();
         // the tile is free again: its values are in HBM (an activation that landed meanwhile has re-queued it already)
-        if (OWN && tid == 9) __hip_atomic_store(&P.own_lock[own_slot_now], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (OWN && tid == 9) { UFM_STRICT_RELEASE(); __hip_atomic_store(&P.own_lock[own_slot_now], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
         if (tid < 9) {
             const int dr = tid / 3 - 1, dc = tid % 3 - 1;
             if (tid == 4) {
@@ -3730,7 +3744,11 @@ int ufm_debug_lmax(ufm_t *p, int32_t *out, int n) {      // diagnostics array of
     return hipMemcpy(out, p->e->P.lmax, sizeof(int) * n, hipMemcpyDeviceToHost) == hipSuccess ? UFM_OK : UFM_ERR_HIP_BASE;
 }
 int ufm_tile_edge(void) { return T; }
+#ifdef UFM_STRICT_FENCES
+const char *ufm_version(void) { return "ufm-gfx950 0.1 (block-FIM, strict-fence checking build)"; }
+#else
 const char *ufm_version(void) { return T == 32 ? "ufm-gfx950 0.1 (block-FIM, tile 32)" : "ufm-gfx950 0.1 (block-FIM, tile 16)"; }
+#endif
 
 int ufm_create(ufm_t **out, int algo, int opt_lvl, int use_heuristic, int device_id) {
     if (!out) return UFM_ERR_INVALID;
