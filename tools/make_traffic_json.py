@@ -52,6 +52,11 @@ out = {
     },
 }
 out.update(main)
+reg = out["other_instantiations"]["k_replan_region<0> (block-resident replan: both phases of a replan in one workgroup)"]
+out["region_traffic_bytes_per_launch"] = reg["traffic_bytes_per_launch"]      # bench.py: roofline_replans.traffic
+if bench and "roofline_replans" in bench:
+    out["region_bench_avg_launch_us_same_run"] = bench["roofline_replans"]["avg_launch_us"]
+    out["region_traffic_over_algorithmic"] = reg["traffic_bytes_per_launch"] / bench["roofline_replans"]["algorithmic_bytes_per_launch"]
 if bench and "roofline" in bench:
     out["bench_avg_launch_us_same_run"] = bench["roofline"]["avg_launch_us"]
     out["algorithmic_bytes_per_launch_same_run"] = bench["roofline"]["algorithmic_bytes_per_launch"]
