@@ -26,7 +26,11 @@ extern "C" {
 
 typedef struct ufm_planner ufm_t;
 
-/* planner family: FieldDPlanner / ShiftedGridPlanner / DFMPlanner */
+/* planner family: FieldDPlanner / ShiftedGridPlanner / DFMPlanner.  (MS-DFM: both opt levels relax the level-1 planner's
+ * operator -- the smallest of the eight per-neighbour candidates of min_rhs_decreased_neighbor, DynamicFastMarching_impl.h:270-313
+ * --; level 0 differs by having no Info member.  min_rhs<0> has the same fixed point in exact arithmetic; in fp32 the reference's
+ * own level-0 planner does not terminate on the larger maps, and the level-1 operator's field is the closer one to it where it
+ * does: DESIGN.md section 6.) */
 enum { UFM_ALGO_FD = 0, UFM_ALGO_SG = 1, UFM_ALGO_DFM = 2 };
 
 /* return codes */

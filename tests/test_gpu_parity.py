@@ -379,6 +379,31 @@ def test_first_plan_large(algo, size, seed):
     g.close()
 
 
+@pytest.mark.parametrize("seed", [1000, 1003])
+def test_dfm_level0_at_1024(seed):
+    """MS-DFM level 0 (DFMPlanner<0>, min_rhs<0>: the better cell of each opposite pair, one quadratic per stencil) against the
+    oracle's level-0 planner at the largest size of the config-4 maps where that one terminates (1024^2: one map's worth of
+    expansions; at 2048^2 seed 1000 it does not), plan and five replans, under the one DFM bound
+    (helpers.DFM_RTOL).  The engine serves a level-0 planner with the level-1 operator (the smallest of the eight
+    per-neighbour candidates): same fixed point in exact arithmetic, and in fp32 CLOSER to the reference's level-0 field than
+    iterating min_rhs<0> itself with the creep cut-offs that needs (24 maps 256^2..1024^2: <= 1.03e-6 against <= 2.45e-6;
+    seed 1003 is the map on which the level-0 operator broke the bound)."""
+    size = 1024
+    cost = ufm_amd.synth.cost_map(seed, size, size)
+    start, goal = ufm_amd.synth.start_goal(size, size)
+    o, g = make_pair(ALGOS["DFM"], 0, cost, start, goal)
+    assert o.step() == 0 and g.step() == 0
+    assert g.stats.launches < 4000
+    n, nbad = check_parity(o, g, "DFM-0/%d seed %d" % (size, seed), below_start_key=True)
+    assert n > 0.9 * size * size
+    for k, s, top, left, patch in ufm_amd.synth.replan_script(seed, size, size, n_patches=5):
+        for p in (o, g):
+            p.patch_map(patch, top, left); p.set_start(*s)
+            assert p.step() == 0
+        check_parity(o, g, "DFM-0/%d seed %d replan %d" % (size, seed, k), below_start_key=True)
+    g.close()
+
+
 def test_patches_accumulate_until_the_next_step():
     """Several patch_map calls before one step() (overlapping, one of them a no-op) are all
     propagated -- a superset of the reference, which keeps only the last patch's change list

@@ -23,14 +23,9 @@ constexpr int NTHR = 1024;     // 16 waves; four lanes per node, each wave owns 
 #ifndef UFM_STEP_FILTER
 #define UFM_STEP_FILTER 1        // do not wake a neighbour tile whose border is less than one step above this tile's (see k_relax write-back)
 #endif
-#ifndef UFM_DFM_LAX_VISITS
-#define UFM_DFM_LAX_VISITS 16     // DFM: after this many visits of a tile in one step a 1-ulp rise is rounding noise
-#endif
-#ifndef UFM_DFM_QUIET_VISITS
-#define UFM_DFM_QUIET_VISITS 24   // DFM: ... and a decrease of <= 4 ulp no longer wakes the neighbours
-#endif
-// Level 1 (ALGO_DFM1) converges without such cut-offs on almost every map; they are its livelock guard only: block
-// Gauss-Seidel between two tiles can cycle through a finite set of last-bit states (2048^2, seed 1006)
+// MS-DFM (operator ALGO_DFM1 below) converges without cut-offs on almost every map; these are its livelock guard only: block
+// Gauss-Seidel between two tiles can cycle through a finite set of last-bit states (2048^2, seed 1006): after LAX visits of a tile
+// in one step a 1-ulp rise is left alone, after QUIET visits a change of <= 4 ulp no longer wakes the neighbours
 #ifndef UFM_DFM1_LAX_VISITS
 #define UFM_DFM1_LAX_VISITS 64
 #endif
@@ -96,16 +91,17 @@ constexpr int CTS = ((T + 1) * (T + 1) + 127) / 128 * 128;       // bytes per co
 constexpr float SQRT2F = 1.41421356237309504880168872420969807856967187537694f;  // Macros.cpp:2
 
 enum { MODE_LOWER = 0, MODE_RAISE = 1 };
-// Kernel-side operator ids: the three planner families of include/ufm.h plus the level-1 form of MS-DFM.
-// DFMPlanner<1> never evaluates min_rhs<0>'s "best cell of each pair, then one quadratic per stencil" while it
-// lowers: every expansion offers each neighbour ONE candidate built on the expanded cell itself
-// (min_rhs_decreased_neighbor, DynamicFastMarching_impl.h:270-313) and RHS keeps the smallest (plan<1> :79-86).
-// Its consistent field is therefore the fixed point of "min over the eight per-neighbour candidates" -- which
-// is not the level-0 operator at the ulp level: the float quadratic is not monotone, so Q(min(a,b), .) and
-// min(Q(a, .), Q(b, .)) differ in the last bit where two fronts meet.  Measured on the oracle's 1024^2 field:
-// 0 of 1.02 M interior elements violate G = F1(G), 259 violate G = F0(G).
+// Kernel-side operator ids: FD and SG as in include/ufm.h, and ONE operator for MS-DFM, the level-1 form (id 3; UFM_ALGO_DFM = 2 is the
+// family's id at the C ABI and never a template argument).  DFMPlanner<1> never evaluates min_rhs<0>'s "best cell of each pair, then one
+// quadratic per stencil" while it lowers: every expansion offers each neighbour ONE candidate built on the expanded cell itself
+// (min_rhs_decreased_neighbor, DynamicFastMarching_impl.h:270-313) and RHS keeps the smallest (plan<1> :79-86).  Its consistent field is the
+// fixed point of "min over the eight per-neighbour candidates" -- not the level-0 operator at the ulp level: the float quadratic is not
+// monotone, so Q(min(a,b), .) and min(Q(a, .), Q(b, .)) differ in the last bit where two fronts meet (oracle's 1024^2 field: 0 of 1.02 M
+// interior elements violate G = F1(G), 259 violate G = F0(G)).  A level-0 planner is served by the same operator: iterating F0 itself needs
+// creep cut-offs to terminate (rounds 1-2) and lands FARTHER from the reference's level-0 field than the fixed point of F1 does -- 24 maps,
+// 256^2..1024^2: <= 2.45e-6 / 27 ulp with 60-90 % of the elements off, against <= 1.03e-6 / 10 ulp with 0.3-33 %.
 constexpr int ALGO_DFM1 = 3;
-template <int ALGO> constexpr bool is_dfm = (ALGO == UFM_ALGO_DFM || ALGO == ALGO_DFM1);
+template <int ALGO> constexpr bool is_dfm = (ALGO == ALGO_DFM1);
 
 constexpr int LMAX = 8192;
 constexpr int INFBITS = 0x7F800000;   // +inf as int: non-negative floats order like their bits

@@ -337,12 +337,10 @@ int Engine::relax_kernel(int mode, int k_arg, float rbound, int grid) {
     if (mode == MODE_LOWER) {
         if (algo == UFM_ALGO_FD) UFM_LAUNCH(UFM_ALGO_FD, MODE_LOWER);
         else if (algo == UFM_ALGO_SG) UFM_LAUNCH(UFM_ALGO_SG, MODE_LOWER);
-        else if (opt_lvl == 0) UFM_LAUNCH(UFM_ALGO_DFM, MODE_LOWER);
         else UFM_LAUNCH(ALGO_DFM1, MODE_LOWER);
     } else {
         if (algo == UFM_ALGO_FD) UFM_LAUNCH(UFM_ALGO_FD, MODE_RAISE);
         else if (algo == UFM_ALGO_SG) UFM_LAUNCH(UFM_ALGO_SG, MODE_RAISE);
-        else if (opt_lvl == 0) UFM_LAUNCH(UFM_ALGO_DFM, MODE_RAISE);
         else UFM_LAUNCH(ALGO_DFM1, MODE_RAISE);
     }
 #undef UFM_LAUNCH
@@ -413,12 +411,10 @@ int Engine::launch_relax(int mode, float rbound, hipEvent_t e0, hipEvent_t e1) {
     if (mode == MODE_LOWER) {
         if (algo == UFM_ALGO_FD) UFM_LAUNCH(UFM_ALGO_FD, MODE_LOWER);
         else if (algo == UFM_ALGO_SG) UFM_LAUNCH(UFM_ALGO_SG, MODE_LOWER);
-        else if (opt_lvl == 0) UFM_LAUNCH(UFM_ALGO_DFM, MODE_LOWER);
         else UFM_LAUNCH(ALGO_DFM1, MODE_LOWER);
     } else {
         if (algo == UFM_ALGO_FD) UFM_LAUNCH(UFM_ALGO_FD, MODE_RAISE);
         else if (algo == UFM_ALGO_SG) UFM_LAUNCH(UFM_ALGO_SG, MODE_RAISE);
-        else if (opt_lvl == 0) UFM_LAUNCH(UFM_ALGO_DFM, MODE_RAISE);
         else UFM_LAUNCH(ALGO_DFM1, MODE_RAISE);
     }
 #undef UFM_LAUNCH
@@ -470,7 +466,6 @@ int Engine::owned_phase() {
 #endif
     if (algo == UFM_ALGO_FD) UFM_LAUNCH(UFM_ALGO_FD);
     else if (algo == UFM_ALGO_SG) UFM_LAUNCH(UFM_ALGO_SG);
-    else if (opt_lvl == 0) UFM_LAUNCH(UFM_ALGO_DFM);
     else UFM_LAUNCH(ALGO_DFM1);
 #undef UFM_LAUNCH
     k_own_export<<<256, 256, 0, stream>>>(P, k + 1);
@@ -828,8 +823,7 @@ int Engine::step(ufm_stats *out) {
                            else k_replan_region<A><<<g, b, 0, stream>>>(P, rjs, h_ctr, h_flag); } while (0)
             if (algo == UFM_ALGO_FD) UFM_LAUNCH(UFM_ALGO_FD);
             else if (algo == UFM_ALGO_SG) UFM_LAUNCH(UFM_ALGO_SG);
-            else if (opt_lvl == 0) UFM_LAUNCH(UFM_ALGO_DFM);
-            else UFM_LAUNCH(ALGO_DFM1);
+                    else UFM_LAUNCH(ALGO_DFM1);
 #undef UFM_LAUNCH
             HIPCHK(hipGetLastError());
             last_active = 1;

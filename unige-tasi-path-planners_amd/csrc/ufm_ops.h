@@ -95,14 +95,6 @@ template <int ALGO> struct QuadConsts;
 // load_at: `cost(r, c)` returns the traversal cost (float, +inf = obstacle / outside) of entry (r, c) of the staged
 // cost window -- row r, column c <-> cell (x0 + r - off, y0 + c - off), off = 1 for node planners; (lx, ly) is the
 // element inside the staged block.  load(): the tile kernel's float window Cs with pitch CP.
-template <> struct QuadConsts<UFM_ALGO_DFM> {
-    float th;   // lane 0: cost (orthogonal stencil, h = 1); lane 1: cost*SQRT2 (diagonal stencil)
-    template <class CostAt> __device__ __forceinline__ void load_at(CostAt cost, int lx, int ly, int q, int /*gpitch*/) {
-        const float tau = cost(lx, ly);
-        th = (q & 1) ? tau * SQRT2F : tau;
-    }
-    __device__ __forceinline__ void load(const float *Cs, int lx, int ly, int q) { load_at([=](int r, int c) { return Cs[r * CP + c]; }, lx, ly, q, GP); }
-};
 template <> struct QuadConsts<ALGO_DFM1> {
     float th;   // lanes 0, 1: cost (h = 1); lanes 2, 3: cost*SQRT2 (= cost * HYPOT(+-1, +-1))
     int so, po; // LDS offsets: +-so = the lane's two neighbours, +-po = the perpendicular pair of the same stencil
@@ -183,14 +175,7 @@ template <int ALGO, int GPITCH = GP>
 __device__ __forceinline__ LaneEval eval_quad_w(const float *ctr, int q, const QuadConsts<ALGO> &C) {
     LaneEval e;
     e.gV = e.gH = e.gD = 0.0f;
-    if constexpr (ALGO == UFM_ALGO_DFM) {
-        e.r = INFINITY;
-        if (q < 2) {
-            const int a = q ? -GPITCH - 1 : -GPITCH, b = q ? GPITCH + 1 : GPITCH, c = q ? GPITCH - 1 : -1, d = q ? -GPITCH + 1 : 1;
-            e.r = q_dfm(fminf(ctr[a], ctr[b]), fminf(ctr[c], ctr[d]), C.th);
-        }
-        e.h = false;
-    } else if constexpr (ALGO == ALGO_DFM1) {
+    if constexpr (ALGO == ALGO_DFM1) {
         const float pm = fminf(ctr[-C.po], ctr[C.po]);
         const float a = q_dfm(ctr[-C.so], pm, C.th), b = q_dfm(ctr[C.so], pm, C.th);
         e.h = b < a;
@@ -210,8 +195,7 @@ __device__ __forceinline__ LaneEval eval_quad_w(const float *ctr, int q, const Q
 template <int ALGO>
 __device__ __forceinline__ int bp_byte(const LaneEval &e, int q, const QuadConsts<ALGO> &C, bool winner) {
     int code, dep = 3;
-    if constexpr (ALGO == UFM_ALGO_DFM) code = q;
-    else code = (q << 1) | (e.h ? 1 : 0);
+    code = (q << 1) | (e.h ? 1 : 0);
     if constexpr (ALGO == UFM_ALGO_SG) dep = dep_sg(e.h ? e.gH : e.gV, e.gD, C.k);
     if constexpr (ALGO == UFM_ALGO_FD) {
         TriFD t;
@@ -246,16 +230,7 @@ __device__ __forceinline__ float eval_quad_bp(const float *ctr, int q, const Qua
 // ctr points at the node inside the LDS tile; returns this lane's share of RHS(node)
 template <int ALGO, int GPITCH = GP>
 __device__ __forceinline__ float eval_quad(const float *ctr, int q, const QuadConsts<ALGO> &C) {
-    if constexpr (ALGO == UFM_ALGO_DFM) {
-        // DynamicFastMarching_impl.h:157-210: best_cell (:344-351) is a min on values, and
-        // "diag < ortho ? diag : ortho" is the quad min of the two stencil solves
-        float r = INFINITY;
-        if (q < 2) {
-            const int a = q ? -GPITCH - 1 : -GPITCH, b = q ? GPITCH + 1 : GPITCH, c = q ? GPITCH - 1 : -1, d = q ? -GPITCH + 1 : 1;
-            r = q_dfm(fminf(ctr[a], ctr[b]), fminf(ctr[c], ctr[d]), C.th);
-        }
-        return r;
-    } else if constexpr (ALGO == ALGO_DFM1) {
+    if constexpr (ALGO == ALGO_DFM1) {
         // DynamicFastMarching_impl.h:270-313 for the two neighbours of this lane's axis: g_a = G(nbr), g_b = the
         // better cell of the perpendicular pair; RHS = the smallest of the eight candidates (plan<1> :79-86)
         const float pm = fminf(ctr[-C.po], ctr[C.po]);

@@ -501,7 +501,7 @@ __global__ __launch_bounds__(NTHR) void k_replan_region(DevParams P, RegionJobs 
     // ---- 2b. the back-pointers (what k_finalize_bp does for the launch chain's steps): every node of a patch in which a value changed, and of
     // the patches around it -- a neighbour's value may be what it was and still come from another triangle now --, evaluated once more on the
     // values as they stand, the arg-min kept.  (MS-DFM level 0 has none.)
-    if constexpr (ALGO != UFM_ALGO_DFM) {
+    {
         const int w = tid >> 6, lane = tid & 63, q = lane & 3, nd = lane >> 2;
         const int nprow = J.ntx * TP, npcol = J.nty * TP;
         auto cost_at = [=](int r, int c) { const int b = Cb[r * RCP + c]; return b >= thr ? INFINITY : (float)b; };

@@ -392,18 +392,14 @@ __global__ __launch_bounds__(OWNK == 2 ? NTHR / 2 : NTHR, UFM_RELAX_WAVES) void 
         // ... and which neighbours have to hear of it.  Bit 0: the one across this element's row border, 1: across its column border,
         // 2: the diagonal one, 3: this tile itself (a border value that rose)
         auto wb_need = [&](int wb_r, int wb_c, float gf, float gl0) -> int {
-            // DFM only: the float fixed point of the upwind quadratic is not unique;
-            // neighbouring tiles can push each other's border values up one ulp at a time for tens of
-            // thousands of launches.  An INCREASE of at most 4 ulp (a rounding-level correction, never
-            // new information) is stored but does not wake the neighbour; after 24 visits of a tile in
-            // one step the same holds for decreases.  Well inside DFM's 1e-6 tolerance.
+            // MS-DFM only: the float fixed point of the upwind quadratic is not unique; two neighbouring tiles can
+            // push each other's border values through a finite set of last-bit states for ever (2048^2, seed 1006, seen once).  The
+            // livelock guard: in a tile that has come back more than UFM_DFM1_QUIET_VISITS times in one step a change of at most
+            // 4 ulp is stored but does not wake the neighbour.
             bool significant = true;
             if (is_dfm<ALGO> && MODE == MODE_LOWER && gf < INFINITY && gl0 < INFINITY) {
                 const int du = __float_as_int(gf) - __float_as_int(gl0);
-                // (level 1: only in a tile that keeps coming back -- the rises of its operator are corrections of
-                //  values latched from transient neighbours and have to travel)
-                if (ALGO == UFM_ALGO_DFM ? (du > 0 ? du <= 4 : (s_misc[1] > UFM_DFM_QUIET_VISITS && du >= -4))
-                                         : (s_misc[1] > UFM_DFM1_QUIET_VISITS && du >= -4 && du <= 4)) significant = false;
+                if (s_misc[1] > UFM_DFM1_QUIET_VISITS && du >= -4 && du <= 4) significant = false;
             }
             const int er = (wb_r == 0) ? -1 : ((wb_r == T - 1) ? 1 : 0);
             const int ec = (wb_c == 0) ? -1 : ((wb_c == T - 1) ? 1 : 0);
@@ -540,7 +536,7 @@ __global__ __launch_bounds__(OWNK == 2 ? NTHR / 2 : NTHR, UFM_RELAX_WAVES) void 
         int ew_pend = 0;      // ... border values of this wave are on their way to HBM, the neighbours have not been queued yet
         // early hand-off and in-visit refresh (resident kernel, node planners) -- ew_flush, halo_poll, halo_refresh --: ufm_relax_early.inc
 #include "ufm_relax_early.inc"
-        const bool lax = is_dfm<ALGO> && (s_misc[1] > (ALGO == ALGO_DFM1 ? UFM_DFM1_LAX_VISITS : UFM_DFM_LAX_VISITS));
+        const bool lax = is_dfm<ALGO> && s_misc[1] > UFM_DFM1_LAX_VISITS;
         bool conv = false;
 #ifdef UFM_TIMING
         const bool wtrace_on = DYN && MODE == MODE_LOWER && k == UFM_TRACE_K0 && i == 0;
