@@ -6,18 +6,9 @@ import ufm_amd
 
 ALGOS = {"FD": 0, "SG": 1, "DFM": 2}
 
-# Acceptance bounds on the reference's consistent set, each defined HERE and nowhere else.
-# FD / SG: SURVEY.md 8(d)'s max(1e-6*G, 2 ulp) -- and every FD / SG test asserts bit equality on top of it.
-FIELD_RTOL = 1e-6
-# MS-DFM: 2e-6*G, derived once from the reference algorithm's own spread (reproducible with
-# tools/dfm_fixed_points.py): the float fixed point of DFM's update operator is not unique, and WHICH one an
-# evaluation order lands on is already a last-bits matter between two sequential orders of the reference's own
-# level-1 operator -- the priority-queue order (the oracle) against raster Gauss-Seidel sweeps of the same
-# candidates differ by up to 9 ulp = 1.02e-6 on the 2048^2 maps of BASELINE config 4 (seed 1003); the reference's
-# level-0 planner does not terminate at all on one of them (seed 1000: 1e9 expansions, oracle code -75).  So
-# 1e-6 cannot be promised by anything that does not replay the queue's pop order; the bound is twice the
-# measured spread.  Measured engine-vs-oracle on those eight maps: 4-8 ulp, <= 7.5e-7.
-DFM_RTOL = 2e-6
+# Acceptance bounds on the reference's consistent set: defined in the package (ufm_amd.tolerances), nowhere else.
+FIELD_RTOL = ufm_amd.tolerances.FIELD_RTOL
+DFM_RTOL = ufm_amd.tolerances.DFM_RTOL
 
 
 def rtol_for(algo):

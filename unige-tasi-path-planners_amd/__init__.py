@@ -15,3 +15,4 @@ from . import capi  # noqa: F401
 from . import synth  # noqa: F401
 from . import episode  # noqa: F401
 from . import harness  # noqa: F401
+from . import tolerances  # noqa: F401

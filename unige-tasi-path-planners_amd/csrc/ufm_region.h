@@ -18,6 +18,9 @@
 // published to the spinning host; otherwise the host carries on with the ordinary launch chain from the queues.
 // A sweep budget bounds every wave (livelock guard): what is still dirty when it runs out goes to the queues too.
 
+#ifndef UFM_REGION_IDLE_SLEEP_RAISE
+#define UFM_REGION_IDLE_SLEEP_RAISE 16    // ... in the node planners' invalidation phase, whose sweeps are a few loads and a compare
+#endif
 #ifndef UFM_REGION_IDLE_SLEEP
 #define UFM_REGION_IDLE_SLEEP 16          // an idle wave of the block kernel looks at its wake words this often (x 64 clocks): 1 / 4 / 16 / 32 / 64 -> 100 replans 18.9 / 18.0 / 17.6 / 17.6 / 17.8 ms (the looks of twelve idle waves take issue slots and LDS cycles from the four that sweep)
 #endif
@@ -292,7 +295,7 @@ __device__ void region_phase(const DevParams &P, const RegionJob &J, float *Gs, 
         if (!vote) {                                                         // nothing to do: idle until woken or all idle
             if (lane == 0) atomicAdd(&S.idle, 1);
             for (;;) {
-                __builtin_amdgcn_s_sleep(UFM_REGION_IDLE_SLEEP);
+                __builtin_amdgcn_s_sleep((MODE == MODE_RAISE && !is_dfm<ALGO>) ? UFM_REGION_IDLE_SLEEP_RAISE : UFM_REGION_IDLE_SLEEP);
                 // (all loads first, then the decisions: one LDS round trip per look)
                 const int idle_now = __hip_atomic_load(&S.idle, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 const int gave_up_now = __hip_atomic_load(&S.giveup, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);

@@ -202,7 +202,7 @@ __global__ __launch_bounds__(OWNK == 2 ? NTHR / 2 : NTHR, UFM_RELAX_WAVES) void 
                     // resident when the others had left (the device was shared) must not wait out a limit of its own
                     if (aborted == 2) stop = true;            // workgroup 0 has seen the end
                     else if (stop) __hip_atomic_store(&P.ctr->own_abort, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    const bool late = !stop && (aborted || wall_clock64() - own_t0 > P.own_limit || s_own[2] > 16000);
+                    const bool late = !stop && (aborted || wall_clock64() - own_t0 > P.own_limit);
                     if (late) { atomicAdd(&P.ctr->own_stops, 1); __hip_atomic_store(&P.ctr->own_abort, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
                     const bool taking = take && !stop && !late;
                     int r_old = INFBITS, r_lk = 1;
@@ -713,7 +713,7 @@ __global__ __launch_bounds__(OWNK == 2 ? NTHR / 2 : NTHR, UFM_RELAX_WAVES) void 
             const bool take = b != ~0ull && !(s_gmin & 2) && !(P.own_flags & 1) && !s_late;
             if (tid == 0) {
                 own_commit(b, take, false, own_ro, own_rl);
-                if (wall_clock64() - own_t0 > P.own_limit || s_own[2] > 16000) s_late = 1;   // (a workgroup that is never out of work looks at the clock here)
+                if (wall_clock64() - own_t0 > P.own_limit) s_late = 1;   // (a workgroup that is never out of work looks at the clock here)
             }
             own_next = __builtin_amdgcn_readfirstlane(take ? own_base + (int)(unsigned int)b : -1);
         }

@@ -1,0 +1,14 @@
+"""Acceptance bounds of the parity checks on the reference's consistent set, each defined HERE and nowhere else (tests/helpers.py and
+__graft_entry__.smoke() import them).
+
+FD / SG: SURVEY.md 8(d)'s max(1e-6 * G, 2 ulp) -- and every FD / SG test asserts bit equality on top of it.
+
+MS-DFM: 2e-6 * G.  Self-derived -- the reference holds no fixture for it, so this part of the parity is unpinned: the float fixed point
+of DFM's update operator is not unique, and WHICH one an evaluation order lands on is already a last-bits matter between two sequential
+orders of the reference's own level-1 operator as the ORACLE restates it (tools/dfm_fixed_points.py: the priority-queue order against
+raster Gauss-Seidel sweeps of the same candidates differ by up to 9 ulp = 1.02e-6 on the 2048^2 maps of BASELINE config 4, seed 1003);
+the restated level-0 planner does not terminate at all on one of them (seed 1000: 1e9 expansions, oracle code -75).  So 1e-6 cannot be
+promised by anything that does not replay the queue's pop order; the bound is twice the measured spread.  Measured engine-vs-oracle on
+those eight maps: 4-8 ulp, <= 7.5e-7."""
+FIELD_RTOL = 1e-6
+DFM_RTOL = 2e-6
