@@ -23,13 +23,20 @@ for i in range(n):
     scripts.append(list(ufm_amd.synth.replan_script(1000 + i, size, size, n_patches=a.patches)))
 t0 = time.perf_counter(); assert b.step() == 0; t1 = time.perf_counter()
 cells = 0
+per_round, launches = [], []
 for k in range(a.patches):
+    tr = time.perf_counter()
     for i in range(n):
         _, s, top, left, patch = scripts[i][k]
         b.patch_map(i, patch, top, left); b.set_start(i, *s)
     assert b.step() == 0
     cells += b.stats.expanded
-    if os.environ.get('VERBOSE'): print(k, b.stats.launches, b.stats.region_replans_done, b.stats.region_replans)
+    per_round.append((time.perf_counter() - tr) * 1e6); launches.append(b.stats.launches)
 t2 = time.perf_counter()
 print("%s %d x %d^2: plan %.1f ms; %d batch replans %.2f ms each (%d launches in the last step, %.0f cells per step); block kernel finished %d of %d map replans alone" % (
     a.algo, n, size, (t1 - t0) * 1e3, a.patches, (t2 - t1) * 1e3 / a.patches, b.stats.launches, cells / a.patches, b.stats.region_replans_done, b.stats.region_replans))
+pr, la = np.array(per_round), np.array(launches)
+one = la == 1
+print("  rounds the block kernel finished alone: %d, %.0f us each; the others: %d, %.0f us each, launches per round min / median / max %s" % (
+    one.sum(), pr[one].mean() if one.any() else 0, (~one).sum(), pr[~one].mean() if (~one).any() else 0,
+    (int(la[~one].min()), int(np.median(la[~one])), int(la[~one].max())) if (~one).any() else None))

@@ -254,6 +254,8 @@ static int engine_set_param(Engine *e, const char *name, double value) {
     else if (!std::strcmp(name, "region_band")) e->region_band = (float)value;
     else if (!std::strcmp(name, "region_ahead")) e->region_ahead = (int)value;
     else if (!std::strcmp(name, "region_tiles")) e->region_tiles = value < 3 ? 3 : (value > RTMAX ? RTMAX : (int)value);
+    else if (!std::strcmp(name, "cont_raise")) e->cont_raise = value < 0 ? 0 : (int)value;
+    else if (!std::strcmp(name, "cont_lower")) e->cont_lower = value < 0 ? 0 : (int)value;
     else if (!std::strcmp(name, "region_sweeps")) e->region_sweeps = value < 16 ? 16 : (int)value;
     else if (!std::strcmp(name, "batch_margin")) e->batch_margin = (int)value;
     else if (!std::strcmp(name, "raise_margin")) e->raise_margin = (float)value;

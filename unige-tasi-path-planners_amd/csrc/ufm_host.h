@@ -64,6 +64,10 @@ struct Engine {
     int region_debug = 0;
     float region_band = 1.5f;        // ordering band of the block's lowering sub-rounds, in patch crossings at the mean cost (0: unordered)
     uint32_t region_runs = 0, region_done = 0;   // replans submitted to the block kernel / completed by it alone
+    uint32_t region_cont = 0, region_cont_done = 0;   // ... continued by one blind submission of the launch chain / completed by that
+    int cont_raise = 4, cont_lower = 8;          // launches of that submission per phase (0: straight to the adaptive loop -- MS-DFM, whose leftovers are
+                                                 // chains of 20-40 band steps, mostly invalidation: measured, config 4, 903 us per such round either way;
+                                                 // sending the leftover lowering through the resident kernel instead: 1 111 us)
     int batch_margin = 1;            // replans: launches per phase = most that the last 6 replans needed + this
     float raise_margin = 0.25f;      // invalidation bound = start key + this many ordering bands (a miss costs a second round)
     ReplanJob *h_job = nullptr;      // host-coherent pinned: per-replan inputs of the graph's first node
@@ -914,6 +918,31 @@ int Engine::step(ufm_stats *out) {
         fast_done = h_ctr->done != 0;
         if (regioned) {
             st.launches += 1u;
+            if (!fast_done && spin_wait && cont_lower > 0) {
+                // The block kernel has left work beyond its block (3 of the headline's 100 replans; a round of a batch as soon as ONE of its maps
+                // has): the launch chain takes over from the queues -- first as ONE blind submission ending in the device-side end check, like
+                // the fused replan path (a few launches that may find nothing to do are cheaper than the adaptive loop's host round trips:
+                // that loop cost a batch round of config 4 ~0.6 ms), and only if that was not enough through the adaptive loop below.
+                // (one invalidation launch even when the block kernel saw nothing to invalidate below its bound: the end check reads what the
+                //  last launch of each phase released)
+                const int nr2 = skip_raise ? 1 : std::max(1, cont_raise), nl2 = cont_lower;
+                last_active = 1;
+                k_unpark<<<1, 1024, 0, stream>>>(P, Q_RAISE, iter[Q_RAISE], -1.0f);       // (-1: the bound the block kernel left in the counters)
+                for (int i = 0; i < nr2; ++i) launch_relax(MODE_RAISE, -1.0f);
+                k_raise_to_lower<<<1, 1024, 0, stream>>>(P, iter[Q_LOWER]);
+                for (int i = 0; i < nl2; ++i) launch_relax(MODE_LOWER, INFINITY);
+                ++pub_seq;
+                k_replan_end<<<64, T * T, 0, stream>>>(P, iter[Q_RAISE], iter[Q_LOWER], band, h_ctr, h_flag, pub_seq);
+                finalize_bp(1);
+                HIPCHK(hipGetLastError());
+                int rc = wait_published();
+                if (rc != UFM_OK) return rc;
+                fast_done = h_ctr->done != 0;
+                st.raise_launches += (uint32_t)nr2;
+                st.launches += (uint32_t)(nr2 + nl2);
+                skip_raise = false;
+                ++region_cont; if (fast_done) ++region_cont_done;
+            }
         } else {
         st.raise_launches += (uint32_t)nr;
         st.launches += (uint32_t)(nr + nl);
@@ -1087,6 +1116,7 @@ int engine_create(Engine **out, int n_maps, int algo, int opt_lvl, int use_heuri
     // twice the sweeps per tile; a wider band and an earlier re-queue suit it better (plan 60 -> 52 ms)
     // -- for a single map; a batch is throughput-bound and keeps the less redundant setting (8 x 2048^2: 484 vs 476 M cells/s)
     if (algo == UFM_ALGO_DFM && n_maps == 1) { e->delta_scale = e->delta_scale_long = 2.5f; e->max_iters = 16; }
+    if (algo == UFM_ALGO_DFM) e->cont_lower = 0;
     e->maps.resize(n_maps);
     hipDeviceProp_t prop;
     HIPCHK(hipGetDeviceProperties(&prop, device_id));
