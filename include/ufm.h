@@ -204,6 +204,11 @@ int ufm_batch_set_heuristic_multiplier(ufm_batch_t *b, float mult);
 int ufm_batch_set_map(ufm_batch_t *b, int i, const uint8_t *host_map, int width, int length);
 int ufm_batch_set_map_device(ufm_batch_t *b, int i, const uint8_t *dev_map, int width, int length);
 int ufm_batch_patch_map(ufm_batch_t *b, int i, const uint8_t *host_patch, int x, int y, int w, int h);
+/* Lifetime of dev_patch: a patch of at most 4096 cells handed to a batch of more than one map is applied by ONE launch for all maps
+ * at the next ufm_batch_step (or ufm_batch_read_map / _extract_path / _set_map, whichever comes first), not at the call: the buffer must
+ * stay valid and unchanged until that call has returned (bench.py: the receive buffer of the round's broadcast, reused two rounds
+ * later).  ufm_batch_set_param(b, "defer_patches", 0) applies every patch at the call, stream-ordered, like ufm_patch_map_device of a
+ * single planner and like a batch of one map -- at one launch per patch. */
 int ufm_batch_patch_map_device(ufm_batch_t *b, int i, const uint8_t *dev_patch, int x, int y, int w, int h);
 int ufm_batch_set_start(ufm_batch_t *b, int i, float x, float y);
 int ufm_batch_set_goal(ufm_batch_t *b, int i, float x, float y);
