@@ -36,7 +36,7 @@ class ExpandedMap {
 
   /** Filled by size(): every element that holds a finite value, as (elem, (g, rhs[, info])) pairs in
    * one bucket per 256x256 block -- what the reference's `for (auto b : map.buckets)` dump iterates.
-   * info (level-1/2 planners): the back-pointer(s) ufm_read_info derives from the field. */
+   * info (level-1/2 planners): the engine's stored back-pointer(s), ufm_read_info. */
   std::vector<bucket_> buckets;
 
   ExpandedMap() = default;
