@@ -27,6 +27,7 @@ for rep in range(3):
         p.patch_map_device(d_patches[i].data_ptr(), top, left, 31, 31); p.set_start(*s)
         assert p.step() == 0
         times.append(time.perf_counter() - t); cells += p.stats.expanded; visits += p.stats.tile_visits; evals += p.stats.elem_evals
+        if times[-1] > 1e-3: print("   slow replan %d: %.0f us, launches %d (raise %d), region done %d/%d, expanded %d, visits %d, u_ms %.2f p_ms %.2f" % (i, times[-1] * 1e6, p.stats.launches, p.stats.raise_launches, p.stats.region_replans_done, p.stats.region_replans, p.stats.expanded, p.stats.tile_visits, p.stats.u_ms, p.stats.p_ms), flush=True)
     ts = np.array(times) * 1e6
     print("%s %d^2 %s: plan %.2f ms; 100 replans %.2f ms (median %.0f us, p90 %.0f, max %.0f); block kernel %d/%d done; cells %d visits %d patch-sweeps/replan %d launches(last) %d back-pointers %s" % (
         algo, size, params, t_plan * 1e3, ts.sum() / 1e3, np.median(ts), np.percentile(ts, 90), ts.max(),
