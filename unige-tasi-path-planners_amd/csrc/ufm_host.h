@@ -47,8 +47,7 @@ struct Engine {
     bool use_owned = true;           // plans: the lowering phase as ONE resident launch (k_relax<.,LOWER,false,1|2>) instead of a launch per band step
     float owned_limit_ms = -1.0f;    // ... which hands back to the launch chain after this long, whatever happens (< 0: by the size of the job,
                                      //     ~15 x what a plan of that many tiles takes: a device shared with another long-running kernel)
-    float owned_band = -1.0f;        // ... ordering band in tile crossings (< 0: twice delta_scale_long -- nobody waits for a launch to end
-                                     //     here, and a workgroup that finds nothing inside the band idles: wider pays)
+    float owned_band = -1.0f;        // ... ordering band in tile crossings (< 0: by the job -- 2.5 for a single map of a node planner, 3 for MS-DFM, 2 for a batch: owned_phase())
     uint32_t owned_launches = 0;
     hipEvent_t own_ev[2] = {nullptr, nullptr};
     hipEvent_t reg_ev[2] = {nullptr, nullptr};     // profiling: around the block kernel of a replan
@@ -440,7 +439,12 @@ int Engine::launch_relax(int mode, float rbound, hipEvent_t e0, hipEvent_t e1) {
 // for launch iter + 1, which run_phase() then finds.
 int Engine::owned_phase() {
     const int k = iter[Q_LOWER];
-    const float delta = delta_abs >= 0.0f ? delta_abs : (owned_band >= 0.0f ? owned_band : 2.0f * delta_scale_long) * T * mean_cost;
+    // the ordering band in tile crossings.  Round 2: 4 (a workgroup that finds nothing inside the band idles, so wider paid).  With the idle
+    // workgroups' looks made cheap (round 3) the optimum moved down -- 4096^2 FD 14.7 / 14.2 / 14.2 / 14.2 / 14.6 ms for 1.5 / 2 / 2.5 / 3 / 4 with 230 k ... 350 k
+    // visits, 8192^2 36.7 / 35.8 / 35.5 / 36.0 / 37.4, SG 2048^2 5.85 / 5.4 / 5.3 / 5.4 / 5.7; MS-DFM 2048^2 12.0 / 11.8 / 11.4 / 11.7 (2 ... 4); the 8-map
+    // MS-DFM batch, bound by the number of visits: 34.0 / 34.3 / 34.9 / 35.8 (2 ... 4)
+    const float band_auto = nmaps > 1 ? 2.0f : (algo == UFM_ALGO_DFM ? 3.0f : 2.5f);
+    const float delta = delta_abs >= 0.0f ? delta_abs : (owned_band >= 0.0f ? owned_band : band_auto) * T * mean_cost;
     const double limit_ms = owned_limit_ms >= 0.0f ? (double)owned_limit_ms : 200.0 + (double)P.NT / 250.0;   // (4096^2: 0.46 s; its plan takes 17 ms)
     P.own_limit = (unsigned long long)(limit_ms * 1e5);   // 100 MHz ticks
     P.own_flags = owned_flags;
