@@ -161,7 +161,7 @@ __global__ void k_own_import(DevParams P, int k) {
         g_tile[0][t] = 0xFFFFFFFFu; g_tile[1][t] = 0u; g_tile[2][t] = 0xFFFFFFFFu; g_tile[3][t] = 0u; g_tile[4][t] = 0u;
         g_push64[t] = ~0ull;
     }
-    if (blockIdx.x == 0 && threadIdx.x == 0) g_nvis = 0u;
+    if (blockIdx.x == 0 && threadIdx.x == 0) { g_nvis = 0u; g_nplog = 0u; }
 #endif
     const int r = k % 3, rz = (k + 2) % 3;
     const int n = P.ctr->cnt[Q_LOWER][r];

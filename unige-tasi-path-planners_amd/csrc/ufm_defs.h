@@ -313,6 +313,15 @@ constexpr int VIS_DIAG_MAX = 1 << 20;
 __device__ unsigned long long g_push64[TILE_DIAG_MAX];     // per tile: {time, sender} of the earliest activation not yet taken
 __device__ unsigned int g_vis[VIS_DIAG_MAX][5];
 __device__ unsigned int g_nvis;
+// events around the corner tiles (0..1, 0..1) of map 0: {time, a, b, c}; b = 0xFFFFFFFF: workgroup 0 saw the end; 0xFFFFFFFE: in-visit refresh
+// (a = tile, c = what the exchange returned); 0xFFFFFFFD: a look of the owner (a = workgroup, c = its best priority); else an activation a -> b with priority c
+constexpr int PLOG_MAX = 1 << 14;
+__device__ unsigned int g_plog[PLOG_MAX][4];
+__device__ unsigned int g_nplog;
+__device__ __forceinline__ void plog(unsigned int a, unsigned int b, unsigned int c) {
+    const unsigned int i = atomicAdd(&g_nplog, 1u);
+    if (i < PLOG_MAX) { g_plog[i][0] = (unsigned int)(wall_clock64() - g_tile_t0); g_plog[i][1] = a; g_plog[i][2] = b; g_plog[i][3] = c; }
+}
 #endif
 // -DUFM_STRICT_FENCES (a checking build, libufm_strict.so: tests/test_strict_fences.py holds the product build to it bit for bit): the
 // textbook form of the protocol -- an agent-scope release fence in front of every activation and of every lock release, an agent-scope
@@ -336,6 +345,7 @@ __device__ __forceinline__ void own_push(const DevParams &P, int gt, int pbits, 
         const unsigned int now = (unsigned int)(wall_clock64() - g_tile_t0);
         atomicMin(&g_tile[2][gt], now);
         atomicMin(&g_push64[gt], ((unsigned long long)now << 32) | (unsigned int)from);
+        if (gt / P.TY < 2 && gt % P.TY < 2) plog((unsigned int)from, (unsigned int)gt, (unsigned int)pbits);
     }
 #endif
 }

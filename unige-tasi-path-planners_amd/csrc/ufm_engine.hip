@@ -82,6 +82,14 @@ int ufm_debug_visits(unsigned int *out, int cap) {   // out[cap][5]; returns the
     if (n && hipMemcpyFromSymbol(out, HIP_SYMBOL(g_vis), sizeof(unsigned int) * 5 * n) != hipSuccess) return UFM_ERR_HIP_BASE;
     return (int)n;
 }
+int ufm_debug_plog(unsigned int *out, int cap) {     // out[cap][4]
+    unsigned int n = 0;
+    if (hipMemcpyFromSymbol(&n, HIP_SYMBOL(g_nplog), sizeof(n)) != hipSuccess) return UFM_ERR_HIP_BASE;
+    if ((int)n > cap) n = cap;
+    if (n > PLOG_MAX) n = PLOG_MAX;
+    if (n && hipMemcpyFromSymbol(out, HIP_SYMBOL(g_plog), sizeof(unsigned int) * 4 * n) != hipSuccess) return UFM_ERR_HIP_BASE;
+    return (int)n;
+}
 int ufm_debug_sdiag(unsigned long long *out, int reset) {
     if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(g_sdiag), sizeof(unsigned long long) * 16) != hipSuccess) return UFM_ERR_HIP_BASE;
     if (reset) { unsigned long long z[16] = {}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_sdiag), z, sizeof(z)) != hipSuccess) return UFM_ERR_HIP_BASE; }

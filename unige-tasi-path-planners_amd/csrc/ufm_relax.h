@@ -183,11 +183,21 @@ __global__ __launch_bounds__(OWNK == 2 ? NTHR / 2 : NTHR, UFM_RELAX_WAVES) void 
                         __syncthreads();
                         unsigned long long acc = 0ull;
                         bool mine_ok = true;
+                        // (eight loads in flight per thread instead of 153 dependent round trips per pass on a 4096^2 map.  What is left to gain
+                        //  here: with no collect at all the product build's 14.2 ms plan kernel is 0.15-0.2 ms shorter -- profiles/r3_end_of_phase.txt)
 #pragma unroll 1
-                        for (int e = tid; e < total; e += NTH) {
-                            const int v = __hip_atomic_load(&P.own_prio[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                            if (v < INFBITS || v >= OWN_MARK) mine_ok = false;
-                            acc += ((unsigned long long)(unsigned int)v + 1ull) * (0x9E3779B97F4A7C15ull + 2ull * (unsigned long long)e);
+                        for (int e0 = tid; e0 < total; e0 += NTH * 8) {
+                            int v[8];
+#pragma unroll
+                            for (int u = 0; u < 8; ++u) v[u] = __hip_atomic_load(&P.own_prio[min(e0 + u * NTH, total - 1)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+                            for (int u = 0; u < 8; ++u) {
+                                const int e = e0 + u * NTH;
+                                if (e < total) {
+                                    if (v[u] < INFBITS || v[u] >= OWN_MARK) mine_ok = false;
+                                    acc += ((unsigned long long)(unsigned int)v[u] + 1ull) * (0x9E3779B97F4A7C15ull + 2ull * (unsigned long long)e);
+                                }
+                            }
                         }
                         for (int o_ = 32; o_; o_ >>= 1) acc += (unsigned long long)__shfl_xor((long long)acc, o_);
                         if (lane == 0) atomicAdd(&s_best, acc);
@@ -202,6 +212,9 @@ __global__ __launch_bounds__(OWNK == 2 ? NTHR / 2 : NTHR, UFM_RELAX_WAVES) void 
                     // resident when the others had left (the device was shared) must not wait out a limit of its own
                     if (aborted == 2) stop = true;            // workgroup 0 has seen the end
                     else if (stop) __hip_atomic_store(&P.ctr->own_abort, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#ifdef UFM_TIMING
+                    if (blockIdx.x == 0) plog(stop ? 1u : 0u, stop ? 0xFFFFFFFFu : 0xFFFFFFFDu, (unsigned int)(b >> 32));
+#endif
                     const bool late = !stop && (aborted || wall_clock64() - own_t0 > P.own_limit);
                     if (late) { atomicAdd(&P.ctr->own_stops, 1); __hip_atomic_store(&P.ctr->own_abort, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
                     const bool taking = take && !stop && !late;
@@ -776,6 +789,7 @@ __global__ __launch_bounds__(OWNK == 2 ? NTHR / 2 : NTHR, UFM_RELAX_WAVES) void 
                 const unsigned long long tk3 = wall_clock64();
                 if (OWN && gt < TILE_DIAG_MAX && (!EARLY || (s_qw[1] & 0x10000))) g_tile[1][gt] = (unsigned int)(tk3 - g_tile_t0);
                 if (OWN && s_misc_vi < VIS_DIAG_MAX) g_vis[s_misc_vi][2] = (unsigned int)(tk3 - g_tile_t0);
+                if (OWN && gt / P.TY < 2 && gt % P.TY < 2) plog((unsigned int)gt, 0xFFFFFFFBu, (conv ? 1u : 0u) | ((unsigned int)s_misc[3] << 8) | ((unsigned int)blockIdx.x << 20));
                 if (EARLY) atomicAdd(&g_tdiag[6], (unsigned long long)(s_qw[1] & 0xFFFF));   // in-visit refreshes
                 atomicAdd(&g_tdiag[0], tk1 - tk0); atomicAdd(&g_tdiag[1], tk2 - tk1); atomicAdd(&g_tdiag[2], tk3 - tk2);
                 atomicAdd(&g_tdiag[3], 1ull);
