@@ -43,12 +43,12 @@ for rep in range(reps):
         continue
     d = ~((ref == g) | (np.isinf(ref) & np.isinf(g)))
     below = d & (np.minimum(ref, g) < min(key, ref_key))
+    nb = int((d & ~below).sum())
     if algo == "DFM":
         if below.any():
             worst = max(worst, float((np.abs(ref[below] - g[below]) / np.maximum(np.abs(ref[below]), 1.0)).max()))
         below = below & (np.abs(ref - g) > ufm_amd.tolerances.DFM_RTOL * np.maximum(np.abs(ref), 1.0))
     below_diff += int(below.sum())
-    nb = int((d & ~below).sum())
     beyond_diff += nb
     beyond_runs += nb > 0
 print("%s %d^2 seed %d %s: %d runs; elements below the start's key (%.3f) that differ from the first run%s: %d; beyond the key: %d elements in %d runs; "
