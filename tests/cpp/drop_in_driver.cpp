@@ -54,6 +54,30 @@ int run(int size, const std::vector<uint8_t> &raster, int n_patches, const std::
                 planner.num_nodes_updated, map.get_rhs(Elem(sn.x, sn.y)), map.get_interp_rhs(sn),
                 (int)map.consistent(Elem(sn.x, sn.y)), grid.get_cost(Cell(hdr[0], hdr[1])));
   }
+  // the queue as a caller can observe it (the public member ReplannerBase::priority_queue, ReplannerBase.h:154): the elements that are
+  // not consistent; after a step none of them has a key below the start's (end_condition()).  NO_HEURISTIC: Key = float = min(g, rhs)
+  {
+    const auto &q = planner.priority_queue;
+    float start_key = 0;                       // max over the start elements that have been reached (end_condition, FD impl:225-256)
+    if (std::is_same<Elem, Cell>::value) { start_key = map.get_g(Elem(Cell(next_point).x, Cell(next_point).y)); }
+    else {
+      const Cell sc(next_point);
+      for (int dx = 0; dx < 2; ++dx) for (int dy = 0; dy < 2; ++dy) { const float v = map.get_g(Elem(sc.x + dx, sc.y + dy)); if (v < INFINITY) start_key = std::fmax(start_key, v); }
+    }
+    bool ordered = true, inconsistent = true, field_g = true;
+    int i = 0;
+    float prev = -INFINITY;
+    for (auto it = q.ordered_begin(); it != q.ordered_end(); ++it, ++i) {
+      if (it->key < prev) ordered = false;
+      prev = it->key;
+      const auto gr = q.g_rhs(i);
+      if (gr.first == gr.second) inconsistent = false;
+      if (map.get_g(it->elem) != gr.first) field_g = false;
+    }
+    std::printf("queue size %d empty %d top_key %.9g start_key %.9g ordered %d inconsistent %d field_g %d top_is_first %d err %d\n", q.size(), (int)q.empty(),
+                q.empty() ? INFINITY : (double)q.top_key(), (double)start_key, (int)ordered, (int)inconsistent, (int)field_g,
+                (int)(q.empty() || (q.top_value().x == q.begin()->elem.x && q.top_value().y == q.begin()->elem.y)), q.last_error());
+  }
   // the `tof` dump (main.cpp:139-156)
   const long long n = (long long)planner.map.size();
   double sum = 0;

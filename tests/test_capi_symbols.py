@@ -21,6 +21,13 @@ def test_header_and_binding_list_agree():
     assert _declared() == sorted(capi.SYMBOLS)
 
 
+def test_header_tolerance_is_the_tested_one():
+    """the MS-DFM bound the queue view uses (include/ufm.h) is the one the parity tests hold the planner to"""
+    txt = open(os.path.join(ROOT, "include", "ufm.h")).read()
+    m = re.search(r"#define\s+UFM_DFM_RTOL\s+([0-9.eE+-]+)f", txt)
+    assert m and float(m.group(1)) == ufm_amd.tolerances.DFM_RTOL
+
+
 def test_library_exports_every_symbol():
     if not os.path.exists(ufm_amd.library_path()):
         ufm_amd.build_library()

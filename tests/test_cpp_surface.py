@@ -68,6 +68,14 @@ def test_driver_matches_python_binding(tmp_path, algo):
         if algo != "DFM":
             assert np.float32(m.group(4)) == g[sx, sy]
         assert float(m.group(6)) == float(cur[top, left])     # the host-side Graph mirror followed the patch
+    # the queue view (ReplannerBase::priority_queue, the mirror's PriorityQueue.h): ordered by key, every entry inconsistent and holding
+    # the field's G, nothing below the start's key (DFM: within its tolerance)
+    m = re.match(r"queue size (\d+) empty (\d) top_key (\S+) start_key (\S+) ordered (\d) inconsistent (\d) field_g (\d) top_is_first (\d) err (-?\d+)", lines[-2])
+    assert m, lines[-2]
+    assert (int(m.group(1)) == 0) == (int(m.group(2)) == 1)
+    assert m.group(5) == m.group(6) == m.group(7) == m.group(8) == "1" and int(m.group(9)) == 0
+    if int(m.group(1)):
+        assert float(m.group(3)) >= float(m.group(4)) * (1 - (2e-6 if algo == "DFM" else 0.0))
     # the `tof` dump: map.size() == elements iterated over map.buckets == elements with a value when the field is probed through
     # get_g, in the driver's own process (elements beyond the start's key are not final: which of them hold a value is not
     # the same from run to run, so another run's count is only a sanity bound)

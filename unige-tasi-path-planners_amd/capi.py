@@ -23,7 +23,7 @@ SYMBOLS = [
     "ufm_batch_read_field", "ufm_extract_path", "ufm_batch_extract_path", "ufm_read_info", "ufm_read_info_derived",
     "ufm_check_layout", "ufm_batch_check_layout", "ufm_batch_set_param", "ufm_check_info", "ufm_batch_check_info",
     "ufm_batch_create_sharded", "ufm_batch_shards", "ufm_batch_set_heuristic_multiplier", "ufm_batch_set_map_device",
-    "ufm_batch_patch_map_device", "ufm_batch_read_map", "ufm_batch_set_profiling", "ufm_batch_stream",
+    "ufm_batch_patch_map_device", "ufm_batch_read_map", "ufm_batch_set_profiling", "ufm_batch_stream", "ufm_read_queue",
 ]
 
 
@@ -120,6 +120,7 @@ def load_library():
     L.ufm_check_layout.argtypes = [vp, vp, vp]
     L.ufm_batch_check_layout.argtypes = [vp, vp, vp]
     L.ufm_check_info.argtypes = [vp, vp]
+    L.ufm_read_queue.argtypes = [vp, i, vp, vp, vp]
     L.ufm_batch_check_info.argtypes = [vp, vp]
     L.ufm_batch_set_param.argtypes = [vp, C.c_char_p, C.c_double]
     L.ufm_set_param.argtypes = [vp, C.c_char_p, C.c_double]
@@ -302,6 +303,19 @@ class Planner:
         out = (C.c_uint64 * 6)()
         _chk(self.L.ufm_check_info(self.h, C.addressof(out)), "ufm_check_info")
         return tuple(int(v) for v in out)
+
+    def read_queue(self, cap=None):
+        """the reference's priority_queue as a caller could observe it between two steps: the elements that are not consistent.
+        Returns (xy int32 [n, 2], g float32 [n], rhs float32 [n], total); n = min(total, cap), cap None: all of them"""
+        total = C.c_int(0)
+        if cap is None:
+            _chk(self.L.ufm_read_queue(self.h, 0, None, None, C.addressof(total)), "ufm_read_queue")
+            cap = total.value
+        xy = np.zeros((max(cap, 1), 2), np.int32)
+        gr = np.zeros((max(cap, 1), 2), np.float32)
+        _chk(self.L.ufm_read_queue(self.h, cap, xy.ctypes.data, gr.ctypes.data, C.addressof(total)), "ufm_read_queue")
+        n = min(total.value, cap)
+        return xy[:n], gr[:n, 0].copy(), gr[:n, 1].copy(), total.value
 
 
 class BatchPlanner:

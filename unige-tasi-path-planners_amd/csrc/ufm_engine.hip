@@ -396,6 +396,7 @@ void *ufm_batch_stream(ufm_batch_t *b, int shard) { return (b && shard >= 0 && s
 
 int ufm_read_info(ufm_t *p, int x0, int y0, int nx, int ny, int32_t *info) { return p ? engine_read_info(p->e, 0, x0, y0, nx, ny, info, false) : UFM_ERR_INVALID; }
 int ufm_read_info_derived(ufm_t *p, int x0, int y0, int nx, int ny, int32_t *info) { return p ? engine_read_info(p->e, 0, x0, y0, nx, ny, info, true) : UFM_ERR_INVALID; }
+int ufm_read_queue(ufm_t *p, int cap, int32_t *xy, float *g_rhs, int *total) { return p ? engine_read_queue(p->e, 0, cap, xy, g_rhs, total) : UFM_ERR_INVALID; }
 int ufm_extract_path(ufm_t *p, int max_steps, int lookahead, int allow_indirect,
                      float *path_xy, int cap_points, float *step_costs, int cap_costs, ufm_path_info *info) {
     return p ? engine_extract_path(p->e, max_steps, lookahead, allow_indirect, path_xy, cap_points, step_costs, cap_costs, info) : UFM_ERR_INVALID;

@@ -1339,6 +1339,43 @@ int engine_extract_path(Engine *e, int max_steps, int lookahead, int allow_indir
     return UFM_OK;
 }
 
+// The elements the reference would hold in its priority queue after the step: G != RHS (k_queue_scan, ufm_path.h).
+int engine_read_queue(Engine *e, int m, int cap, int32_t *xy, float *g_rhs, int *total) {
+    if (!e || m < 0 || m >= e->nmaps || !e->allocated || !total || cap < 0 || (cap > 0 && (!xy || !g_rhs))) return UFM_ERR_INVALID;
+    if (!e->maps[m].goal_set) return UFM_ERR_INVALID;
+    HIPCHK(hipSetDevice(e->device));
+    const size_t words = (size_t)std::max(cap, 1) * 4 + 1;          // [cap][2] int32, [cap][2] float, the count
+    if (words > e->d_info_cap) {
+        if (e->d_info) { HIPCHK(hipStreamSynchronize(e->stream)); hipFree(e->d_info); e->d_info = nullptr; e->d_info_cap = 0; }
+        HIPCHK(hipMalloc(&e->d_info, words * sizeof(int32_t)));
+        e->d_info_cap = words;
+    }
+    int32_t *d_xy = e->d_info;
+    float *d_gr = reinterpret_cast<float *>(e->d_info + (size_t)std::max(cap, 1) * 2);
+    unsigned int *d_cnt = reinterpret_cast<unsigned int *>(e->d_info + (size_t)std::max(cap, 1) * 4);
+    PathField F{};
+    F.G = e->P.G + (size_t)m * e->P.gstride; F.cost = e->P.cost + (size_t)m * e->P.cstride;
+    F.EX = e->P.EX; F.EY = e->P.EY; F.L = e->P.L; F.W = e->P.W; F.TY = e->P.TY; F.thr = e->thr_uchar;
+    F.cells = (e->algo == UFM_ALGO_DFM); F.indirect = (e->algo == UFM_ALGO_FD);
+    const MapState &ms = e->maps[m];
+    HIPCHK(hipMemsetAsync(d_cnt, 0, sizeof(unsigned int), e->stream));
+    const size_t n = (size_t)e->P.EX * e->P.EY;
+    k_queue_scan<<<(unsigned)std::min<size_t>((n + 255) / 256, 4096), 256, 0, e->stream>>>(F, e->opt_lvl, ms.goal_ex, ms.goal_ey, cap, d_xy, d_gr, d_cnt);
+    hipError_t err = hipGetLastError();
+    unsigned int cnt = 0;
+    if (err == hipSuccess) err = hipMemcpyAsync(&cnt, d_cnt, sizeof(cnt), hipMemcpyDeviceToHost, e->stream);
+    if (err == hipSuccess) err = hipStreamSynchronize(e->stream);
+    HIPCHK(err);
+    *total = (int)cnt;
+    const size_t k = std::min<size_t>(cnt, (size_t)cap);
+    if (k) {
+        HIPCHK(hipMemcpyAsync(xy, d_xy, k * 2 * sizeof(int32_t), hipMemcpyDeviceToHost, e->stream));
+        HIPCHK(hipMemcpyAsync(g_rhs, d_gr, k * 2 * sizeof(float), hipMemcpyDeviceToHost, e->stream));
+        HIPCHK(hipStreamSynchronize(e->stream));
+    }
+    return UFM_OK;
+}
+
 // Back-pointers of a window of elements: the stored codes in the reference's format (k_info_stored), or derived from the field alone
 // (k_info, the checker), ufm_path.h.
 int engine_read_info(Engine *e, int m, int x0, int y0, int nx, int ny, int32_t *info, bool derived) {

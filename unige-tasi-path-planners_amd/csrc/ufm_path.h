@@ -456,11 +456,11 @@ __global__ void k_info_stored(PathField F, const uint8_t *bp, int x0, int y0, in
     out[2 * e] = b0;
     out[2 * e + 1] = b1;
 }
-__global__ void k_info(PathField F, int lvl, int x0, int y0, int nx, int ny, int32_t *out) {
-    const int e = blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= nx * ny) return;
-    const int x = x0 + e / ny, y = y0 + e % ny;
-    int b0 = -1, b1 = -1;
+// RHS of an element as the reference's min_rhs<level>() derives it from the field (and, b0 / b1, the back-pointer(s) it would store).
+// The goal's RHS is 0 by definition (init(), impl:17-21): the caller's business.
+__device__ float derived_rhs(const PathField &F, int lvl, int x, int y, int &b0, int &b1) {
+    b0 = -1; b1 = -1;
+    float out_rhs = INFINITY;
     auto lin = [&](int qx, int qy) { return elem_ok(F, qx, qy) ? qx * F.EY + qy : -2; };
     if (F.cells) {                                        // min_rhs<1>, DynamicFastMarching_impl.h:212-268
         const float tau = raster_cost(F, x, y);
@@ -473,6 +473,7 @@ __global__ void k_info(PathField F, int lvl, int x0, int y0, int nx, int ny, int
             dfm_best(F, x + 1, y - 1, x - 1, y + 1, bx, by, gb);
             const float sd = dfm_stencil(lin(ax, ay), lin(bx, by), ga, gb, tau, PATH_SQRT2, d0, d1);
             if (sd < so) { b0 = d0; b1 = d1; } else { b0 = o0; b1 = o1; }
+            out_rhs = fminf(sd, so);
         }
     } else if (lvl == 2) {                                // ShiftedGridPlanner_impl.h:280-303
         const int DX[4] = {-1, 1, -1, 1}, DY[4] = {-1, -1, 1, 1};        // Graph::neighbors_diag_4
@@ -497,6 +498,7 @@ __global__ void k_info(PathField F, int lvl, int x0, int y0, int nx, int ny, int
                 if (rhs == c) b0 = cwx * F.EY + cwy;
             }
         }
+        out_rhs = rhs;
     } else {                                              // FieldDPlanner_impl.h:196-208, ShiftedGridPlanner_impl.h:266-278
         const int DX[8] = {-1, -1, 0, 1, 1, 1, 0, -1}, DY[8] = {0, -1, -1, -1, 0, 1, 1, 1};   // Graph::neighbors_8
         float rhs = INFINITY;
@@ -511,7 +513,34 @@ __global__ void k_info(PathField F, int lvl, int x0, int y0, int nx, int ny, int
             if (c < rhs) rhs = c;
             if (rhs == c) b0 = qx * F.EY + qy;
         }
+        out_rhs = rhs;
     }
+    return out_rhs;
+}
+__global__ void k_info(PathField F, int lvl, int x0, int y0, int nx, int ny, int32_t *out) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= nx * ny) return;
+    int b0, b1;
+    derived_rhs(F, lvl, x0 + e / ny, y0 + e % ny, b0, b1);
     out[2 * e] = b0;
     out[2 * e + 1] = b1;
+}
+// What the reference would hold in its priority queue: the elements that are not consistent (G != RHS, ReplannerBase.h:110-115), with both
+// values -- the caller makes the keys (calculate_key: min(g, rhs) [+ heuristic]).  In no particular order; *count = how many there are
+// (the first `cap` of them are stored).
+__global__ void k_queue_scan(PathField F, int lvl, int gx, int gy, int cap, int32_t *xy, float *gr, unsigned int *count) {
+    const int n = F.EX * F.EY;
+    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < n; e += gridDim.x * blockDim.x) {
+        const int x = e / F.EY, y = e - x * F.EY;
+        const float g = field_at(F, x, y);
+        int b0, b1;
+        const float r = (x == gx && y == gy) ? 0.0f : derived_rhs(F, lvl, x, y, b0, b1);
+        if (g == r || (g != g && r != r)) continue;
+        // MS-DFM: the float fixed point of the upwind quadratic is not unique -- the field is a fixed point of the
+        // relaxation's evaluation of the candidates, min_rhs<1>() as restated here may round the last bits the other way: within the
+        // planner's tolerance (UFM_DFM_RTOL, include/ufm.h) a cell counts as consistent
+        if (F.cells && fabsf(g - r) <= UFM_DFM_RTOL * fmaxf(fabsf(g), 1.0f)) continue;
+        const unsigned int i = atomicAdd(count, 1u);
+        if (i < (unsigned int)cap) { xy[2 * i] = x; xy[2 * i + 1] = y; gr[2 * i] = g; gr[2 * i + 1] = r; }
+    }
 }

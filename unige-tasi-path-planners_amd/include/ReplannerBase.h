@@ -5,8 +5,10 @@
 // the reference (Tests/Planners/*/main.cpp) compiles against it: reset(), step(),
 // set_occupancy_threshold(), set_heuristic_multiplier(), set_map(), patch_map(), set_start(),
 // set_goal(), get_expanded_map(), get_grid(); u_time / p_time, num_nodes_updated /
-// num_nodes_expanded, grid, map.  What is not here: priority_queue (the engine has no heap; its
-// tile queues live on the device) and enqueue_if_inconsistent().
+// num_nodes_expanded, grid, map, priority_queue -- the last as a read view (PriorityQueue.h: size / empty /
+// top_key / top_value / ordered iteration over the elements that are not consistent, derived from the field;
+// the engine has no heap, its tile queues live on the device).  What is not here: enqueue_if_inconsistent()
+// and the queue's mutators -- nothing outside the device decides what is relaxed next.
 // step() returns LOOP_OK / LOOP_FAILURE_NO_GRAPH / LOOP_FAILURE_NO_GOAL like the reference; a
 // device error is returned as the negative ufm code and kept in last_error.
 #ifndef UFM_REPLANNER_BASE_H
@@ -20,6 +22,7 @@
 #include "ExpandedMap.h"
 #include "Graph.h"
 #include "GridTypes.h"
+#include "PriorityQueue.h"
 #include "ufm.h"
 
 #define LOOP_OK 0
@@ -33,9 +36,10 @@ class ReplannerBase {
   typedef MapElem_ Elem;
   typedef MapInfo_ Info;
   typedef ExpandedMap<MapElem_, MapInfo_> Map;
+  typedef PriorityQueue<QueueKey_, MapElem_> Queue;
   float u_time = 0, p_time = 0;
 
-  void reset() { initialize_search = true; check(ufm_reset(handle_)); }
+  void reset() { initialize_search = true; check(ufm_reset(handle_)); map.invalidate(); priority_queue.invalidate(); }
 
   int step() {
     if (initialize_graph) return LOOP_FAILURE_NO_GRAPH;
@@ -43,6 +47,7 @@ class ReplannerBase {
     ufm_stats st{};
     const int rc = ufm_step(handle_, &st);
     map.invalidate();
+    priority_queue.invalidate();
     if (rc != UFM_OK) { last_error = rc; return rc; }
     u_time = st.u_ms; p_time = st.p_ms;
     num_nodes_updated = st.updated; num_nodes_expanded = st.expanded;
@@ -93,6 +98,7 @@ class ReplannerBase {
   int last_error = 0;
   ufm_stats stats{};
 
+  Queue priority_queue;
   Graph grid;
   Map map;
 
@@ -101,6 +107,20 @@ class ReplannerBase {
     const int rc = ufm_create(&handle_, algo, opt_lvl, use_heuristic ? 1 : 0, device);
     if (rc != UFM_OK) throw std::runtime_error("ufm_create failed with code " + std::to_string(rc) + " (no MI355X / libufm.so?)");
     map.attach(handle_);
+    priority_queue.attach(handle_, [this](const MapElem_ &s, float cost_so_far) { return calculate_key(s, cost_so_far); });
+  }
+
+  /** FieldDPlanner_impl.h:177-186, ShiftedGridPlanner_impl.h (same), DynamicFastMarching_impl.h:146-155 */
+  Key calculate_key(const MapElem_ &s, float cost_so_far) const {
+    if constexpr (std::is_same<Key, float>::value) {
+      (void)s;
+      return cost_so_far;
+    } else {
+      float dist;
+      if constexpr (std::is_same<MapElem_, Node>::value) dist = s.distance(grid.start_pos_);
+      else dist = grid.start_cell_.distance(s);
+      return {cost_so_far + heuristic_multiplier * dist, cost_so_far};
+    }
   }
   ~ReplannerBase() { if (handle_) ufm_destroy(handle_); }
   ReplannerBase(const ReplannerBase &) = delete;
