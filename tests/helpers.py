@@ -67,6 +67,21 @@ def check_parity(o, g, what="", below_start_key=False):
     if o.algo != 2:
         ci = g.check_info()
         assert ci[1:4] == (0, 0, 0), "%s: back-pointer self-check %r" % (what, ci)
+    # ... and no element waits below the start's key: the queue view (ufm_read_queue: G != RHS with RHS derived by the path code's
+    # min_rhs<level>(), an evaluation independent of the relaxation kernels) over the whole field
+    if hasattr(g, "read_queue") and o.start is not None:
+        xy, qg, qrhs, total = g.read_queue()
+        skey = o.start_key()
+        if total and np.isfinite(skey):
+            k = np.minimum(qg, qrhs)
+            if o.use_heuristic:
+                sx, sy = o._start_xy()
+                k = (k + np.float32(o.hm) * np.hypot(np.float32(sx) - xy[:, 0].astype(np.float32),
+                                                    np.float32(sy) - xy[:, 1].astype(np.float32)).astype(np.float32)).astype(np.float32)
+            slack = DFM_RTOL * skey if o.algo == 2 else 0.0
+            i = int(np.argmin(k))
+            assert k[i] >= skey - slack, "%s: element %r (g %r, rhs %r) waits with key %r below the start's key %r" % (
+                what, tuple(xy[i]), float(qg[i]), float(qrhs[i]), float(k[i]), float(skey))
     return n, nbad
 
 
