@@ -129,12 +129,14 @@ def free_port():
     return port
 
 
-def launch_ranks(n, script, argv, timeout_s):
+def launch_ranks(n, script, argv, timeout_s, _attempt=0):
     """Start n rank processes of `script` (one per GPU) and watch ALL of them.  Nothing in this process has touched torch or the
     GPU; the children are fresh interpreters.  Rank 0's stdout is collected (the one JSON line), every rank's stderr goes to a
     file of its own.  The first rank that exits with a non-zero code -- or the timeout -- ends the others (terminate, then kill):
     a rank that died before a collective must not leave the rest waiting in it until the backend's own timeout.  Returns that
-    code (124 for the timeout) after relaying the tail of the failing rank's stderr."""
+    code (124 for the timeout) after relaying the tail of the failing rank's stderr.  The rendezvous port is picked by binding port 0 and
+    closing it again, which another launch on the machine can win: a rendezvous that fails with "address already in use" is started once
+    more on another port (fresh children; not when MASTER_PORT was given)."""
     port = os.environ.get("MASTER_PORT") or str(free_port())
     logdir = tempfile.mkdtemp(prefix="bench_ranks_")
     procs, errs = [], []
@@ -176,6 +178,13 @@ def launch_ranks(n, script, argv, timeout_s):
     for line in out0.read().splitlines():      # the contract is ONE JSON line on stdout; whatever else rank 0 printed goes to stderr
         print(line, file=sys.stdout if line.startswith("{") and rc == 0 else sys.stderr)
     sys.stdout.flush()
+    if rc != 0 and failed is not None and _attempt == 0 and "MASTER_PORT" not in os.environ:
+        errs[failed].seek(0)
+        if "address already in use" in errs[failed].read().lower():
+            for f in errs + [out0]:
+                f.close()
+            print("bench.py: rendezvous port %s was taken, starting the ranks once more on another one" % port, file=sys.stderr)
+            return launch_ranks(n, script, argv, max(1.0, deadline - time.monotonic()), _attempt=1)
     if rc != 0:
         print("bench.py: %s; per-rank stderr in %s" % (
             "rank %d exited with code %d, the other ranks were stopped" % (failed, rc) if failed is not None else "timeout after %.0f s" % timeout_s, logdir),
