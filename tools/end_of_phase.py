@@ -1,13 +1,15 @@
-"""Diagnostic (GPU box, -DUFM_TIMING build: build/exp/libufm_timing.so or RL_LIB=path): how long after the last tile visit does the resident plan
+"""Diagnostic (GPU box, -DUFM_TIMING build: build/exp/libufm_timing.so or lib=path): how long after the last tile visit does the resident plan
 kernel end (workgroup 0's end-of-phase collect, ufm_relax.h), and what happened around the tiles at the start corner in the last microseconds --
 activations, visits (which workgroup, how many sweeps), in-visit refreshes.  FD-1 full plan.
-usage: end_of_phase.py size seed reps [name=value ...]"""
+usage: end_of_phase.py size seed reps [lib=path] [events=1] [name=value ...]   (events=1: the event list of every run, not only the last)"""
 import os, sys, ctypes as C
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import numpy as np, ufm_amd
 size, seed, reps = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])
-ufm_amd.use_library(os.path.join(ROOT, os.environ.get("RL_LIB", "build/exp/libufm_timing.so")))
+kv = dict(a.split("=", 1) for a in sys.argv[4:])
+ufm_amd.use_library(os.path.join(ROOT, kv.pop("lib", "build/exp/libufm_timing.so")))
+events = kv.pop("events", "0") != "0"
 L = ufm_amd.load_library()
 L.ufm_debug_plog.argtypes = [C.c_void_p, C.c_int]
 L.ufm_debug_visits.argtypes = [C.c_void_p, C.c_int]
@@ -15,8 +17,8 @@ cost = ufm_amd.synth.cost_map(seed, size, size)
 start, goal = ufm_amd.synth.start_goal(size, size)
 p = ufm_amd.Planner(ufm_amd.ALGO_FD, 1, False)
 p.set_occupancy_threshold(1)
-for a in sys.argv[4:]:
-    k, v = a.split("="); p.set_param(k, float(v))
+for k, v in kv.items():
+    p.set_param(k, float(v))
 p.set_map(cost)
 T = L.ufm_tile_edge(); TY = (size + 1 + T - 1) // T
 corner = {0: "(0,0)", 1: "(0,1)", TY: "(1,0)", TY + 1: "(1,1)"}
@@ -43,7 +45,6 @@ def dump(tag, events):
     print("---- %s: events around the start corner (time in us before the last event)" % tag)
     for t, s in ev:
         if int(tend) - int(t) < 3000000 and not (s.startswith("WG0 look") and int(tend) - int(t) > 30000): print("  %9.2f  %s" % ((int(t) - int(tend)) / 100.0, s))
-events = os.environ.get("RL_EVENTS", "0") != "0"
 for rep in range(reps):
     p.reset(); p.set_start(*start); p.set_goal(*goal)
     assert p.step() == 0
