@@ -379,6 +379,19 @@ def test_first_plan_large(algo, size, seed):
     g.close()
 
 
+@pytest.mark.parametrize("algo,lvl,size,seed", [("FD", 0, 2048, 3), ("SG", 0, 2048, 3), ("SG", 1, 2048, 3), ("SG", 2, 4096, 7)])
+def test_first_plan_large_other_levels(algo, lvl, size, seed):
+    """the optimisation levels test_first_plan_large does not run, at 2048^2, and the shifted-grid planner at the headline size:
+    bit-equal to the oracle's planner of that level below the start's key (the levels differ in bookkeeping, not in the field)"""
+    cost = ufm_amd.synth.cost_map(seed, size, size)
+    start, goal = ufm_amd.synth.start_goal(size, size)
+    o, g = make_pair(ALGOS[algo], lvl, cost, start, goal)
+    assert o.step() == 0 and g.step() == 0
+    n, nbad = check_parity(o, g, "%s-%d/%d" % (algo, lvl, size), below_start_key=True)
+    assert n > 0.9 * size * size and nbad == 0
+    g.close()
+
+
 @pytest.mark.parametrize("seed", [1000, 1003])
 def test_dfm_level0_at_1024(seed):
     """MS-DFM level 0 (DFMPlanner<0>, min_rhs<0>: the better cell of each opposite pair, one quadratic per stencil) against the
