@@ -9,7 +9,10 @@ ap.add_argument("--maps", type=int, default=8)
 ap.add_argument("--algo", default="DFM")
 ap.add_argument("--patches", type=int, default=30)
 ap.add_argument("--param", action="append", default=[], help="name=value for ufm_batch_set_param")
+ap.add_argument("--lib", default=None, help="another build of the library (path under the repository)")
 a = ap.parse_args()
+if a.lib:
+    ufm_amd.use_library(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), a.lib))
 algo = {"FD": 0, "SG": 1, "DFM": 2}[a.algo]
 n, size = a.maps, a.size
 b = ufm_amd.BatchPlanner(n, algo, 1 if algo != 1 else 2)
