@@ -1,5 +1,5 @@
 """Replans of the headline workload (FD-1 4096^2, 100 patches): time per replan, block kernel completion rate.
-usage: replan_probe.py [size] [algo] [name=value ...]"""
+usage: replan_probe.py [size] [algo] [lib=path] [host=1] [name=value ...]   (host=1: the patches handed over as host buffers, ufm_patch_map)"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -7,6 +7,7 @@ import numpy as np, ufm_amd, torch
 size = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 algo = sys.argv[2] if len(sys.argv) > 2 else "FD"
 params = dict(kv.split("=") for kv in sys.argv[3:])
+host_patches = params.pop("host", "0") != "0"
 if "lib" in params:
     ufm_amd.use_library(os.path.join(ROOT, params.pop("lib")))
 A = {"FD": ufm_amd.ALGO_FD, "SG": ufm_amd.ALGO_SG, "DFM": ufm_amd.ALGO_DFM}[algo]
@@ -24,7 +25,9 @@ for rep in range(3):
     times, cells, visits, evals = [], 0, 0, 0
     for i, (k, s, top, left, patch) in enumerate(script):
         t = time.perf_counter()
-        p.patch_map_device(d_patches[i].data_ptr(), top, left, 31, 31); p.set_start(*s)
+        if host_patches: p.patch_map(patch, top, left)
+        else: p.patch_map_device(d_patches[i].data_ptr(), top, left, 31, 31)
+        p.set_start(*s)
         assert p.step() == 0
         times.append(time.perf_counter() - t); cells += p.stats.expanded; visits += p.stats.tile_visits; evals += p.stats.elem_evals
         if times[-1] > 1e-3: print("   slow replan %d: %.0f us, launches %d (raise %d), region done %d/%d, expanded %d, visits %d, u_ms %.2f p_ms %.2f" % (i, times[-1] * 1e6, p.stats.launches, p.stats.raise_launches, p.stats.region_replans_done, p.stats.region_replans, p.stats.expanded, p.stats.tile_visits, p.stats.u_ms, p.stats.p_ms), flush=True)
