@@ -3,10 +3,11 @@ Tests/run_test.py) for driving a planner process over the two FIFOs -- what `run
 cv2 and matplotlib, reduced to what the planner sees: the map, the circular "field of view"
 patches, the heuristic hint, and the messages of the wire protocol.
 
-cv2 is not a dependency: the 3x3 Gaussian blur, the filled circle and the elliptic dilation are
-restated on numpy arrays.  They follow OpenCV's definitions (kernel [1 2 1]/4 with reflect-101
-borders, x^2 + y^2 <= r^2 disc, 3x3 ellipse = cross) but are not claimed to be bit-identical to it;
-the harness is pinned by its own determinism, not by cv2.
+cv2 is not a dependency: the Gaussian blur, the filled circle and the elliptic dilation are
+restated on numpy arrays, following OpenCV's definitions (fixed-point Gaussian kernel with reflect-101
+borders, x^2 + y^2 <= r^2 disc -- what cv2.circle fills for the radii used here --, 3x3 ellipse = cross).
+Blur, inversion, penalty and reveal are pinned by the reference's own recorded mission log (see gaussian_blur);
+the dilation is not (that mission ran with a C-space diameter of 1).
 """
 import errno
 import os
@@ -18,20 +19,56 @@ import numpy as np
 
 
 # ---- map preparation (run_simulator.py:106-113, run_test.py:98-104) -------------------------
+def gaussian_kernel_fixed(ksize):
+    """cv2.GaussianBlur(img, (k, k), 0) on 8-bit images: the kernel OpenCV >= 4.1 applies in fixed point -- the Gaussian of
+    sigma = 0.3 * ((k - 1) / 2 - 1) + 0.8 (a fixed table for k <= 7) in 8 fractional bits, the rounding error of each coefficient carried
+    to the next one and the centre taking what is left of 256.  k = 13: [1 5 10 19 30 41 44 41 30 19 10 5 1]."""
+    small = {1: [1.0], 3: [0.25, 0.5, 0.25], 5: [0.0625, 0.25, 0.375, 0.25, 0.0625],
+             7: [0.03125, 0.109375, 0.21875, 0.28125, 0.21875, 0.109375, 0.03125]}
+    if ksize in small:
+        k = np.array(small[ksize], np.float64)
+    else:
+        sigma = ((ksize - 1) * 0.5 - 1) * 0.3 + 0.8
+        x = np.arange(ksize) - (ksize - 1) * 0.5
+        k = np.exp(-0.5 / (sigma * sigma) * x * x)
+        k = k / k.sum()
+    out = np.zeros(ksize, np.int64)
+    err, acc = 0.0, 0
+    for i in range(ksize // 2):
+        adj = k[i] * 256 + err
+        v = int(np.rint(adj))
+        err = adj - v
+        out[i] = out[ksize - 1 - i] = v
+        acc += v
+    out[ksize // 2] = 256 - 2 * acc
+    return out
+
+
+def gaussian_blur(img, ksize=3):
+    """separable, reflect-101 borders, both passes exact in integers, one rounding at the end ((v + 2^15) >> 16).
+    With this blur, the penalty and the reveal radius of Simulator/simulator/run_simulator.py:147,171 the reference's recorded
+    mission (Tests/Results/noise-trap/planner_opt0.log) is reproduced to the last printed digit for all its 134 steps
+    (tests/test_reference_mission.py) -- which is what pins this restatement to cv2, not a claim about cv2 in general."""
+    if ksize <= 1:
+        return img.copy()
+    k, r = gaussian_kernel_fixed(ksize), ksize // 2
+    a = np.pad(img.astype(np.int64), r, mode="reflect")
+    h = sum(k[i] * a[:, i:i + img.shape[1]] for i in range(ksize))
+    v = sum(k[i] * h[i:i + img.shape[0], :] for i in range(ksize))
+    return np.clip((v + 32768) >> 16, 0, 255).astype(np.uint8)
+
+
 def gaussian_blur3(img):
-    """3x3 Gaussian, sigma from the kernel size as cv2.GaussianBlur(img, (3, 3), 0): [1 2 1]/4"""
-    a = np.pad(img.astype(np.uint32), 1, mode="reflect")
-    h = a[:, :-2] + 2 * a[:, 1:-1] + a[:, 2:]
-    v = h[:-2, :] + 2 * h[1:-1, :] + h[2:, :]
-    return ((v + 8) >> 4).astype(np.uint8)
+    """3x3 Gaussian as cv2.GaussianBlur(img, (3, 3), 0): [1 2 1]/4"""
+    return gaussian_blur(img, 3)
 
 
-def simulation_data(img_h, low_res_penalty=10):
+def simulation_data(img_h, low_res_penalty=10, filter_size=3):
     """(low-resolution costs, high-resolution costs) of a grey-scale bitmap: cost = ~pixel, 0 -> 1;
-    the low-resolution map is the blurred bitmap plus a saturating penalty"""
+    the low-resolution map is the blurred bitmap plus a saturating penalty (run_test.py: 3 / 10; run_simulator.py: 13 / 15)"""
     h = (~img_h).astype(np.uint8)
     h = h + (h == 0)
-    l = (~gaussian_blur3(img_h)).astype(np.uint8)
+    l = (~gaussian_blur(img_h, filter_size)).astype(np.uint8)
     l = l + (l == 0)
     l = np.minimum(l.astype(np.int32) + low_res_penalty, 255).astype(np.uint8)
     return l, h
