@@ -6,12 +6,14 @@
  * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may
  * load this library.  The product path (libufm.so, HIP) never links it.
  *
- * PARITY PINNING STATUS: pinned on the only outputs of the reference that exist -- the known
- * answers SURVEY.md App. E recorded from the reference compiled there for its own `noise-trap`
- * bitmap: expansions, map size, sum of G over the consistent set and G(start) for all seven
- * planner variants, and points / total_cost / total_dist of the extracted path for DFM, SG and FD.
- * This restatement reproduces every one of them (tests/test_oracle.py).  Beyond those it is
- * "parity unpinned": the reference ships no golden vectors / known-answer tests for this path and
+ * PARITY PINNING STATUS: pinned, for ONE planner configuration, on the one output of the reference itself that its tree
+ * holds: the console log of a whole mission of its Field D* planner process (level 0, heuristic keys) on its own
+ * `noise-trap` bitmap (Tests/Results/noise-trap/planner_opt0.log, an older revision of the sources).  This restatement --
+ * planner, replans under a moving start, path extractor -- replays all 134 closed-loop steps of it to the last printed
+ * digit of every position, path cost and path length, and its first plan's 8760 expansions (tests/test_reference_mission.py;
+ * the first plan of the second log, wall-b, as well).  Everything else -- SG, MS-DFM, the other levels, keys without
+ * heuristic, full fields -- is "parity unpinned": cross-checked against the numbers SURVEY.md App. E recorded from a build of
+ * the reference with stand-in headers (tests/test_oracle.py), which pins nothing.  The reference ships no golden vectors and
  * cannot be compiled in this image (its three header-only dependencies are un-vendored empty
  * submodules; writing stand-ins for them is not allowed), so there is no oracle/_ref build.
  * The restatement follows the reference sources function by function (citations in

@@ -3,7 +3,7 @@ __graft_entry__.smoke() import them).
 
 FD / SG: SURVEY.md 8(d)'s max(1e-6 * G, 2 ulp) -- and every FD / SG test asserts bit equality on top of it.
 
-MS-DFM: 2e-6 * G.  Self-derived -- the reference holds no fixture for it, so this part of the parity is unpinned: the float fixed point
+MS-DFM: 2e-6 * G.  Self-derived -- the reference holds no fixture for MS-DFM (its one recorded mission log is Field D*'s, tests/test_reference_mission.py), so this part of the parity is unpinned: the float fixed point
 of DFM's update operator is not unique, and WHICH one an evaluation order lands on is already a last-bits matter between two sequential
 orders of the reference's own level-1 operator as the ORACLE restates it (tools/dfm_fixed_points.py: the priority-queue order against
 raster Gauss-Seidel sweeps of the same candidates differ by up to 9 ulp = 1.02e-6 on the 2048^2 maps of BASELINE config 4, seed 1003);
