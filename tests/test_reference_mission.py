@@ -74,7 +74,7 @@ def replay(name, planner, read_counts, n_steps=None):
             return
 
 
-def check_mission(name, planner, read_counts, count_expanded):
+def check_mission(name, planner, read_counts, count_expanded, counts=True):
     _, _, _, steps = load(name)
     n = upd_same = exp_same = exp_n = 0
     for k, st, got in replay(name, planner, read_counts):
@@ -83,7 +83,7 @@ def check_mission(name, planner, read_counts, count_expanded):
         assert got["sim_pos"] == st["sim_pos"], (what, got, st)            # ... as the simulator printed it: six decimals
         assert got["patch"] == st["sim_patch"] == st.get("patch", st["sim_patch"]), (what, got, st)   # the simulator's rectangle for it
         assert (got["cost"], got["dist"]) == (st["cost"], st["dist"]), (what, got, st)    # cost and length of the extracted path
-        if "updated" in st:
+        if counts and "updated" in st:
             assert abs(got["updated"] - st["updated"]) <= 2, (what, got, st)
             upd_same += got["updated"] == st["updated"]
         if count_expanded and "expanded" in st:
@@ -93,7 +93,7 @@ def check_mission(name, planner, read_counts, count_expanded):
                 assert got["expanded"] == st["expanded"], (what, got, st)  # the first plan's expansions: 8760
         n += 1
     assert n == len(steps) == 134, (n, len(steps))                          # the replay reaches the goal in the step the reference did
-    assert upd_same >= 124, upd_same
+    assert not counts or upd_same >= 124, upd_same
     if count_expanded:
         assert exp_same >= 80, (exp_same, exp_n)
     return n, upd_same, exp_same, exp_n
@@ -130,4 +130,27 @@ def test_engine_first_plan_of_the_second_log():
     g = ufm_amd.Planner(ufm_amd.ALGO_FD, 0, True)
     k, st, got = next(replay("wall-b", g, lambda p: (p.num_nodes_updated, p.num_nodes_expanded), 1))
     assert (got["pos"], got["patch"], got["cost"], got["dist"]) == (st["pos"], st["sim_patch"], st["cost"], st["dist"])
+    g.close()
+
+
+# The same mission through the planner's other forms.  The log was written by level 0 with heuristic keys; level 1 (the back-pointer variant)
+# and the builds without heuristic keys are the reference's own alternatives for the same search -- same field below the start's key, hence the
+# same paths -- so they have to reproduce the log's positions, path costs and path lengths too (their queue-operation counts are their own).
+OTHER_FORMS = [(1, True), (0, False), (1, False)]
+
+
+@pytest.mark.parametrize("lvl,heur", OTHER_FORMS)
+def test_oracle_other_forms_replay_the_reference_mission_log(lvl, heur):
+    import oracle_py as orc
+    o = orc.OraclePlanner(ufm_amd.ALGO_FD, lvl, heur)
+    n, _, _, _ = check_mission("noise-trap", o, lambda p: (p.num_updated, p.num_expanded), False, counts=False)
+    assert n == 134
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("lvl,heur", OTHER_FORMS)
+def test_engine_other_forms_replay_the_reference_mission_log(lvl, heur):
+    g = ufm_amd.Planner(ufm_amd.ALGO_FD, lvl, heur)
+    n, _, _, _ = check_mission("noise-trap", g, lambda p: (p.num_nodes_updated, p.num_nodes_expanded), False, counts=False)
+    assert n == 134
     g.close()
