@@ -15,8 +15,8 @@ significant digits), path cost and path length of every step.
 
 What the log does NOT pin, said plainly: it comes from an older revision of the reference (it prints lines the current sources have
 commented out, FieldDPlanner_impl.h:65,139) -- its "nodes expanded" agrees with the oracle's num_nodes_expanded in the first plan (8760)
-and in 84 of the 105 replans that print it, its "nodes updated" in all but 9 steps (off by 2 there): counts of queue operations, which
-depend on the revision, not on the field.  The second log (wall-b, a binary bitmap: free cells all cost 1, so paths tie) agrees in its
+and in 84 of the 105 replans that print it, its "nodes updated" in all but 9 steps (2 fewer there: the nine steps whose patch reaches the map's bottom border -- that
+revision evidently did not count two nodes on the border row): counts of queue operations, which depend on the revision, not on the field.  The second log (wall-b, a binary bitmap: free cells all cost 1, so paths tie) agrees in its
 first plan (2258 nodes, cost 1203.34, length 89.0422) and parts one step later, in the sixth digit of a path length.  One planner
 (FD level 0 with heuristic keys), its extractor and the simulator's map preparation are pinned this way; SG / MS-DFM, the other levels and
 the keys without heuristic remain cross-checked only."""
