@@ -14,6 +14,20 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB = None
 
 ALGO_FD, ALGO_SG, ALGO_DFM = 0, 1, 2
+REV_CURRENT, REV_START_CELL_FLOOR, REV_UPDATE_SKIPS_FAR_BORDER, REV_LOG = 0, 1, 2, 3   # ufm_oracle.h: the reference's sources as they stand / the two differences of the revision that wrote its mission logs / both
+CASES = ("FD III (f <= 0)", "FD III (f^2 <= CATH(c,b) [sic])", "FD II (c > b)", "FD I", "FD A (c > b)", "FD B", "FD II (c <= b)", "FD A (c <= b)",
+         "SG B", "SG II", "SG A")
+
+
+def case_counts():
+    """(evaluated, won) per case of compute_optimal_cost since the last reset: dicts keyed by CASES"""
+    ev, won = (C.c_ulong * len(CASES))(), (C.c_ulong * len(CASES))()
+    lib().orc_case_counts(ev, won)
+    return dict(zip(CASES, list(ev))), dict(zip(CASES, list(won)))
+
+
+def case_counts_reset():
+    lib().orc_case_counts_reset()
 
 
 def build():
@@ -32,6 +46,8 @@ def lib():
         L.orc_create.argtypes = [i, i, i]
         L.orc_destroy.argtypes = [vp]
         L.orc_reset.argtypes = [vp]
+        L.orc_set_revision.argtypes = [vp, i]
+        L.orc_case_counts.argtypes = [C.POINTER(C.c_ulong), C.POINTER(C.c_ulong)]
         L.orc_set_occupancy_threshold.argtypes = [vp, f]
         L.orc_set_heuristic_multiplier.argtypes = [vp, f]
         L.orc_set_map.argtypes = [vp, C.c_void_p, i, i]
@@ -75,11 +91,12 @@ def _roundf(v):
 class OraclePlanner:
     """Mirror of the reference planner surface (ReplannerBase.h:39-123)."""
 
-    def __init__(self, algo, opt_lvl=0, use_heuristic=False):
+    def __init__(self, algo, opt_lvl=0, use_heuristic=False, revision=REV_CURRENT):
         self.L = lib()
         self.h = self.L.orc_create(algo, opt_lvl, int(use_heuristic))
         if not self.h:
             raise ValueError("bad algo/opt_lvl")
+        self.L.orc_set_revision(self.h, int(revision))
         self.algo, self.opt_lvl = algo, opt_lvl
         self.use_heuristic = bool(use_heuristic)
         self.hm = 1.0

@@ -64,6 +64,7 @@ struct orc_planner {
     int n_start_nodes;
     int start_set;
     int runaway;   /* the last plan() hit expansion_cap() */
+    int revision;  /* ORC_REV_CURRENT (the sources as they stand) or bits of ORC_REV_LOG (see orc_set_revision) */
 };
 
 /* ---------------- keys: std::pair lexicographic / float --------------- */
@@ -219,21 +220,41 @@ static void enqueue_if_inconsistent(orc_t *p, int e) {
 /* CATH / SQUARE, Macros.h:9-12 */
 static inline float cath(float x, float y) { return sqrtf((float)(x * x) - (float)(y * y)); }
 
+/* Which case of compute_optimal_cost an evaluation took (ORC_CASE_*, ufm_oracle.h) -- bookkeeping for the question "which
+ * branches of the operator does a given run exercise, and which of them ever DECIDE an RHS" (tests/test_reference_mission.py:
+ * what the reference's recorded missions pin and what they do not).  Process-wide, not thread-safe: test infrastructure. */
+static unsigned long g_case_eval[ORC_NCASES], g_case_won[ORC_NCASES];
+static int g_last_case;
+/* Ablations of FD's compute_optimal_cost (test hook, tests/test_reference_mission.py: a branch is PINNED by the reference's mission logs
+ * if the logs are no longer reproduced without it).  bit 0: without the `f^2 <= CATH(c, b)` clause of Type III; bit 1: without Type I
+ * (falls through to A); bit 2: without the whole c > b chain (every triangle through B / II / A as for c <= b); bit 3: Type III pays c instead
+ * of b (= Type B: no walking along the edge in the cheaper cell across it). */
+static int g_fd_ablate;
+void orc_set_fd_ablation(int mask) { g_fd_ablate = mask; }
+#define CASE_RET(k, v) do { g_last_case = (k); ++g_case_eval[(k)]; return (v); } while (0)
+void orc_case_counts(unsigned long *evaluated, unsigned long *won) {
+    for (int i = 0; i < ORC_NCASES; ++i) { if (evaluated) evaluated[i] = g_case_eval[i]; if (won) won[i] = g_case_won[i]; }
+}
+void orc_case_counts_reset(void) {
+    for (int i = 0; i < ORC_NCASES; ++i) g_case_eval[i] = g_case_won[i] = 0;
+}
+
 /* FieldDPlanner_impl.h:292-319 + InterpolatedTraversal.cpp:8-10,125-127,
  * 236-238,324-326,403-405 */
 static float cost_fd(float g1, float g2, float b, float c) {
     if (g1 == INFINITY && g2 == INFINITY) return INFINITY;
     if (c == INFINITY) return INFINITY;
     float f = g1 - g2;
-    if (c > b) {
-        if ((f <= 0) || ((float)(f * f) <= cath(c, b))) return g1 + b;          /* III */
-        else if ((f <= b) && (c > (f * SQRT2))) return g1 + cath(c, f);         /* II  */
-        else if ((f > b) && (c > (b * SQRT2))) return g2 + b + cath(c, b);      /* I   */
-        else return g2 + c * SQRT2;                                             /* A   */
+    if (c > b && !(g_fd_ablate & 4)) {
+        if (f <= 0) CASE_RET(ORC_CASE_FD_III, g1 + ((g_fd_ablate & 8) ? c : b));                     /* III */
+        else if (!(g_fd_ablate & 1) && (float)(f * f) <= cath(c, b)) CASE_RET(ORC_CASE_FD_III_SQ, g1 + b);   /* III by the f^2 <= CATH(c,b) test [sic] */
+        else if ((f <= b) && (c > (f * SQRT2))) CASE_RET(ORC_CASE_FD_II_CGB, g1 + cath(c, f));      /* II  */
+        else if (!(g_fd_ablate & 2) && (f > b) && (c > (b * SQRT2))) CASE_RET(ORC_CASE_FD_I, g2 + b + cath(c, b));   /* I   */
+        else CASE_RET(ORC_CASE_FD_A_CGB, g2 + c * SQRT2);                                           /* A   */
     } else {
-        if (f <= 0) return g1 + c;                                              /* B   */
-        else if ((f * SQRT2) < c) return g1 + cath(c, f);                       /* II  */
-        else return g2 + c * SQRT2;                                             /* A   */
+        if (f <= 0) CASE_RET(ORC_CASE_FD_B, g1 + c);                                                /* B   */
+        else if ((f * SQRT2) < c) CASE_RET(ORC_CASE_FD_II, g1 + cath(c, f));                        /* II  */
+        else CASE_RET(ORC_CASE_FD_A, g2 + c * SQRT2);                                               /* A   */
     }
 }
 /* ShiftedGridPlanner_impl.h:422-436 */
@@ -241,9 +262,9 @@ static float cost_sg(float g1, float g2, float c) {
     if (g1 == INFINITY && g2 == INFINITY) return INFINITY;
     if (c == INFINITY) return INFINITY;
     float f = g1 - g2;
-    if (f <= 0) return g1 + c;
-    else if ((f * SQRT2) <= c) return g1 + cath(c, f);
-    else return g2 + c * SQRT2;
+    if (f <= 0) CASE_RET(ORC_CASE_SG_B, g1 + c);
+    else if ((f * SQRT2) <= c) CASE_RET(ORC_CASE_SG_II, g1 + cath(c, f));
+    else CASE_RET(ORC_CASE_SG_A, g2 + c * SQRT2);
 }
 
 /* compute_optimal_cost(n, p_a, p_b, ga, gb): FieldDPlanner_impl.h:269-320 /
@@ -282,6 +303,7 @@ static float min_rhs0_node(const orc_t *p, int x, int y) {
     static const int cdx[8] = {1, 1, 0, -1, -1, -1, 0, 1};
     static const int cdy[8] = {0, 1, 1, 1, 0, -1, -1, -1};
     float rhs = INFINITY;
+    int win = -1;
     for (int i = 0; i < 8; ++i) {
         int ax = x + cdx[i], ay = y + cdy[i];
         if (valid_elem(p, ax, ay)) {
@@ -289,25 +311,28 @@ static float min_rhs0_node(const orc_t *p, int x, int y) {
             int bx = x + cdx[j], by = y + cdy[j];
             if (valid_elem(p, bx, by)) {
                 float c = coc(p, x, y, ax, ay, bx, by);
-                if (c < rhs) rhs = c;
+                if (c < rhs) { rhs = c; win = g_last_case; }
             } else ++i; /* Graph.cpp:224-226 */
         }
     }
+    if (win >= 0) ++g_case_won[win];
     return rhs;
 }
 /* min_rhs<1>(s, bptr): FieldDPlanner_impl.h:196-208, ShiftedGridPlanner_impl.h:266-278 */
 static float min_rhs1_node(const orc_t *p, int x, int y, int *bptr) {
     float rhs = INFINITY;
+    int win = -1;
     for (int i = 0; i < 8; ++i) {
         int qx = x + N8_DX[i], qy = y + N8_DY[i];
         if (!valid_elem(p, qx, qy)) continue;
         int cx, cy;
         if (ccw_neighbor(p, x, y, qx, qy, &cx, &cy)) {
             float cost = coc(p, x, y, qx, qy, cx, cy);
-            if (cost < rhs) rhs = cost;
+            if (cost < rhs) { rhs = cost; win = g_last_case; }
             if (rhs == cost) *bptr = eidx(p, qx, qy);
         }
     }
+    if (win >= 0) ++g_case_won[win];
     return rhs;
 }
 /* ShiftedGridPlanner_impl.h:280-303 min_rhs<2> */
@@ -652,8 +677,11 @@ static void planner_update(orc_t *p) {
     for (int i = 0; i < p->n_upd; ++i) {
         int cx = p->upd_cells[i] / p->W, cy = p->upd_cells[i] % p->W;
         int cs[4] = {eidx(p, cx, cy), eidx(p, cx + 1, cy), eidx(p, cx, cy + 1), eidx(p, cx + 1, cy + 1)};
-        for (int k = 0; k < 4; ++k)
+        for (int k = 0; k < 4; ++k) {
+            /* the recorded missions' revision left out the corner nodes on the map's far borders (x == L, y == W): orc_set_revision */
+            if ((p->revision & ORC_REV_UPDATE_SKIPS_FAR_BORDER) && (cs[k] / p->ny == p->nx - 1 || cs[k] % p->ny == p->ny - 1)) continue;
             if (!(mark[cs[k]] & 2)) { mark[cs[k]] |= 2; list[cnt++] = cs[k]; }
+        }
     }
     for (unsigned long i = 0; i < cnt; ++i) mark[list[i]] &= 1;
     for (unsigned long i = 0; i < cnt; ++i) update_elem(p, list[i]);
@@ -738,9 +766,23 @@ static void refresh_start_nodes(orc_t *p) {
     for (int k = 0; k < 4; ++k)
         if (valid_elem(p, xs[k], ys[k])) p->start_nodes[p->n_start_nodes++] = eidx(p, xs[k], ys[k]);
 }
+/* Which revision of the reference the restatement follows.  ORC_REV_CURRENT (default): the sources as they stand under
+ * /root/reference.  ORC_REV_LOG: the revision that wrote the two mission logs the reference holds (Tests/Results/{noise-trap,wall-b}/
+ * planner_opt0.log -- they print lines the current sources have commented out, FieldDPlanner_impl.h:65,139).  Two differences were
+ * identified by search against the logs (tools/mission_revision_probe.py), both outside the operators:
+ *   (1) ORC_REV_START_CELL_FLOOR: start_cell_ = Cell(floor(x), floor(y)) -- the cell that CONTAINS the position -- where Cell(const Position&) now rounds
+ *       (Cell.cpp:20-21): the four start nodes of end_condition() (FD impl:225-256) differ whenever a coordinate's fraction is >= 0.5;
+ *       with it the restatement's "nodes expanded" equals the log's in 104 of 105 + 73 of 73 replans (with roundf: 84 + 8);
+ *   (2) ORC_REV_UPDATE_SKIPS_FAR_BORDER: update() (FD impl:118-140) did not take the corner nodes that lie on the map's far borders (x == length, y == width) into its
+ *       set: "nodes updated" is 2 smaller there in exactly the steps whose changed cells touch the bottom row / right column; with it
+ *       133 of 133 + 88 of 88 agree.
+ * With both, the restatement replays BOTH logs closed-loop to the last printed digit -- 134 + 89 steps: position, path cost, path
+ * length, nodes updated, and every "nodes expanded" but one (noise-trap step 119: 272 against 273). */
+void orc_set_revision(orc_t *p, int revision) { p->revision = revision; }
 void orc_set_start(orc_t *p, float x, float y) { /* Graph.cpp:6-10, ReplannerBase.h:94-97 */
     p->start_px = x; p->start_py = y;
-    p->start_cx = (int)roundf(x); p->start_cy = (int)roundf(y);
+    p->start_cx = (int)roundf(x); p->start_cy = (int)roundf(y);            /* Cell(Position), Cell.cpp:20-21 */
+    if (p->revision & ORC_REV_START_CELL_FLOOR) { p->start_cx = (int)floorf(x); p->start_cy = (int)floorf(y); }   /* the recorded missions' revision: see orc_set_revision */
     p->start_nx = (int)roundf(x); p->start_ny = (int)roundf(y);
     p->new_start = 1;
     p->start_set = 1;

@@ -40,6 +40,20 @@ enum { ORC_ALGO_FD = 0, ORC_ALGO_SG = 1, ORC_ALGO_DFM = 2 };
 orc_t *orc_create(int algo, int opt_lvl, int use_heuristic);
 void orc_destroy(orc_t *p);
 
+/* ORC_REV_CURRENT: the reference's sources as they stand (default).  ORC_REV_LOG: the older revision that wrote the reference's two
+ * recorded mission logs -- start cell by truncation, update() without the corner nodes on the far map borders (ufm_oracle.c:
+ * orc_set_revision).  Only tests/test_reference_mission.py uses ORC_REV_LOG. */
+enum { ORC_REV_CURRENT = 0, ORC_REV_START_CELL_FLOOR = 1, ORC_REV_UPDATE_SKIPS_FAR_BORDER = 2, ORC_REV_LOG = 3 };
+void orc_set_revision(orc_t *p, int revision);
+/* which case of compute_optimal_cost (FD impl:292-319, SG :422-436) the evaluations took / which case gave the minimum of a
+ * min_rhs<0/1>() call, since the last reset; process-wide */
+enum { ORC_CASE_FD_III = 0, ORC_CASE_FD_III_SQ, ORC_CASE_FD_II_CGB, ORC_CASE_FD_I, ORC_CASE_FD_A_CGB, ORC_CASE_FD_B, ORC_CASE_FD_II, ORC_CASE_FD_A,
+       ORC_CASE_SG_B, ORC_CASE_SG_II, ORC_CASE_SG_A, ORC_NCASES };
+void orc_case_counts(unsigned long *evaluated, unsigned long *won);
+void orc_case_counts_reset(void);
+/* test hook: FD's compute_optimal_cost without one of its branches (bit 0: the f^2 <= CATH(c,b) clause, 1: Type I, 2: the whole c > b chain); 0 = the operator */
+void orc_set_fd_ablation(int mask);
+
 void orc_reset(orc_t *p);
 void orc_set_occupancy_threshold(orc_t *p, float thr);
 void orc_set_heuristic_multiplier(orc_t *p, float m);

@@ -16,6 +16,9 @@
 
 #include <math.h>
 #include <stddef.h>
+#ifdef ORC_PATH_TRACE   /* diagnostics (tools/wallb_probe.py): every candidate of getPathAdditions on stderr */
+#include <stdio.h>
+#endif
 
 /* ProjectToolkit/Macros.cpp:2 */
 static const float SQRT2 = 1.41421356237309504880168872420969807856967187537694f;
@@ -427,11 +430,17 @@ static padd path_additions(const pctx *c, pos_t p, int do_lookahead, float *step
         float cur = INFINITY;
         padd t = vertex ? from_corner(c, p, ea[e], eb[e], &cur) : from_edge(c, p, ea[e], eb[e], &cur);
         if (t.ns == 0) continue;
+        float la = -1.0f;
         if (do_lookahead && !p_valid_vertex(c, t.steps[t.ns - 1])) {
             float dummy = 0.0f;
-            const float la = path_additions(c, t.steps[t.ns - 1], 0, &dummy).cost_to_goal;
-            if (la > t.cost_to_goal) continue;
+            la = path_additions(c, t.steps[t.ns - 1], 0, &dummy).cost_to_goal;
         }
+#ifdef ORC_PATH_TRACE
+        fprintf(stderr, "%s(%.9g,%.9g) edge %d (%d,%d)-(%d,%d): ns %d end (%.9g,%.9g) cost_to_goal %.9g step %.9g lookahead %.9g%s\n", do_lookahead ? "" : "      la ",
+                p.x, p.y, e, ea[e].x, ea[e].y, eb[e].x, eb[e].y, t.ns, t.steps[t.ns - 1].x, t.steps[t.ns - 1].y, t.cost_to_goal, cur, la,
+                (la > t.cost_to_goal) ? " REJECTED" : (t.cost_to_goal < min_cost ? " best" : (t.cost_to_goal == min_cost ? " TIE" : "")));
+#endif
+        if (la > t.cost_to_goal) continue;
         if (t.cost_to_goal < min_cost) {
             min_cost = t.cost_to_goal;
             best = t;

@@ -270,6 +270,7 @@ static int engine_set_param(Engine *e, const char *name, double value) {
     else if (!std::strcmp(name, "tail_grid")) e->tail_grid = value < 1 ? 1 : (int)value;
     else if (!std::strcmp(name, "profile_stride")) e->profile_stride = value < 1 ? 1 : (int)value;
     else if (!std::strcmp(name, "focused")) e->focused = value != 0.0;
+    else if (!std::strcmp(name, "start_cell_floor")) e->start_cell_floor = value != 0.0;
     else if (!std::strcmp(name, "dynamic")) e->dynamic_mode = value != 0.0;
     else return UFM_ERR_INVALID;
     return UFM_OK;

@@ -101,6 +101,8 @@ struct Engine {
     std::vector<PatchRect> region_rects;   // the rectangles the current step consumes (jobs of the block kernel)
     int iter[2] = {0, 0};            // index k of the next relax launch of each queue (never reset: the queues persist)
     bool focused = true;             // stop at the start's key like the reference (end_condition)
+    bool start_cell_floor = false;   // start_cell_ = the cell that contains the start position (floor) instead of Cell(Position)'s roundf (Cell.cpp:20-21): what the
+                                     // revision of the reference that wrote its two recorded mission logs did (tests/test_reference_mission.py; oracle: ORC_REV_LOG)
     bool dynamic_mode = true;        // long queues: k_triage + cursor hand-out
     float *h_bnd = nullptr;          // pinned [nmaps]
     int last_active = 1;             // queue length at the last host check: long queues go through k_triage
@@ -698,7 +700,7 @@ int Engine::step(ufm_stats *out) {
             for (int i = 0; i < 4; ++i) st_el[4 * m + i] = -1;
             sp[2 * m] = sp[2 * m + 1] = 0.0f;
             if (!ms.start_set) continue;
-            const int cx = (int)std::roundf(ms.start_x), cy = (int)std::roundf(ms.start_y);
+            const int cx = (int)(start_cell_floor ? std::floor(ms.start_x) : std::roundf(ms.start_x)), cy = (int)(start_cell_floor ? std::floor(ms.start_y) : std::roundf(ms.start_y));
             // keys measure from start_pos_ (FD/SG, Position::distance) or from start_cell_ (DFM, Cell::distance)
             sp[2 * m] = (algo == UFM_ALGO_DFM) ? (float)cx : ms.start_x;
             sp[2 * m + 1] = (algo == UFM_ALGO_DFM) ? (float)cy : ms.start_y;
