@@ -25,6 +25,7 @@ Prints ONE JSON line on rank 0.
 import argparse
 import json
 import os
+import shutil
 import socket
 import subprocess
 import sys
@@ -137,7 +138,8 @@ def launch_ranks(n, script, argv, timeout_s, _attempt=0):
     code (124 for the timeout) after relaying the tail of the failing rank's stderr.  The rendezvous port is picked by binding port 0 and
     closing it again, which another launch on the machine can win: a rendezvous that fails with "address already in use" is started once
     more on another port (fresh children; not when MASTER_PORT was given)."""
-    port = os.environ.get("MASTER_PORT") or str(free_port())
+    port_given = bool(os.environ.get("MASTER_PORT"))          # (set and not empty: one test for both decisions below)
+    port = os.environ["MASTER_PORT"] if port_given else str(free_port())
     logdir = tempfile.mkdtemp(prefix="bench_ranks_")
     procs, errs = [], []
     out0 = open(os.path.join(logdir, "rank0.out"), "w+")
@@ -178,11 +180,16 @@ def launch_ranks(n, script, argv, timeout_s, _attempt=0):
     for line in out0.read().splitlines():      # the contract is ONE JSON line on stdout; whatever else rank 0 printed goes to stderr
         print(line, file=sys.stdout if line.startswith("{") and rc == 0 else sys.stderr)
     sys.stdout.flush()
-    if rc != 0 and failed is not None and _attempt == 0 and "MASTER_PORT" not in os.environ:
-        errs[failed].seek(0)
-        if "address already in use" in errs[failed].read().lower():
+    if rc != 0 and failed is not None and _attempt == 0 and not port_given:
+        # (every rank's stderr: the rank that holds the EADDRINUSE message -- rank 0, which binds -- need not be the first one to exit)
+        taken = False
+        for e in errs:
+            e.seek(0)
+            taken = taken or "address already in use" in e.read().lower()
+        if taken:
             for f in errs + [out0]:
                 f.close()
+            shutil.rmtree(logdir, ignore_errors=True)
             print("bench.py: rendezvous port %s was taken, starting the ranks once more on another one" % port, file=sys.stderr)
             return launch_ranks(n, script, argv, max(1.0, deadline - time.monotonic()), _attempt=1)
     if rc != 0:
@@ -202,6 +209,8 @@ def launch_ranks(n, script, argv, timeout_s, _attempt=0):
                 print("---- rank %d stderr ----\n%s" % (r, text), file=sys.stderr)
     for f in errs + [out0]:
         f.close()
+    if rc == 0:
+        shutil.rmtree(logdir, ignore_errors=True)     # (a failed run keeps its per-rank files: the message above names the directory)
     return rc
 
 
@@ -376,6 +385,9 @@ def run_rank(args, planner_factory=None, factory_label=None):
             planner.set_heuristic_multiplier(float(min(c.min() for c in costs)))
         planner.set_occupancy_threshold(1)
         if not rehearsal:
+            # (opt-in: a round's patches sit in the round's receive buffer, which is only written again two rounds later -- so they may be applied
+            #  by one launch at the step that consumes them instead of one launch per map at the call: include/ufm.h)
+            planner.set_param("defer_patches", 1)
             for kv in args.param:
                 planner.set_param(kv.split("=")[0], float(kv.split("=")[1]))
             planner.set_profiling(not args.no_profile)

@@ -26,11 +26,15 @@ extern "C" {
 
 typedef struct ufm_planner ufm_t;
 
-/* planner family: FieldDPlanner / ShiftedGridPlanner / DFMPlanner.  (MS-DFM: both opt levels relax the level-1 planner's
- * operator -- the smallest of the eight per-neighbour candidates of min_rhs_decreased_neighbor, DynamicFastMarching_impl.h:270-313
- * --; level 0 differs by having no Info member.  min_rhs<0> has the same fixed point in exact arithmetic; in fp32 the reference's
- * own level-0 planner does not terminate on the larger maps, and the level-1 operator's field is the closer one to it where it
- * does: DESIGN.md section 6.) */
+/* planner family: FieldDPlanner / ShiftedGridPlanner / DFMPlanner.
+ * MS-DFM, said plainly: (1) level 0 IS the level-1 operator -- both opt levels relax the smallest of the eight per-neighbour candidates of
+ * min_rhs_decreased_neighbor (DynamicFastMarching_impl.h:270-313); a level-0 planner only differs by having no Info member.  min_rhs<0>
+ * (:157-210) has the same fixed point in exact arithmetic, not in fp32; this repository's ORACLE'S RESTATEMENT of the level-0 planner does
+ * not terminate on the larger maps (the reference itself could not be run here), and where it does the level-1 operator's field lies
+ * within 1.03e-6 of it.  (2) The acceptance bound is UFM_DFM_RTOL = 2e-6 relative, SELF-DERIVED from the oracle
+ * (twice the spread of the operator's own float fixed points): the reference holds no MS-DFM fixture, so MS-DFM parity is unpinned.
+ * (3) Results are not bit-reproducible from run to run (asynchronous waves land on different members of that family of fixed points,
+ * measured spread 9.3e-7); Field D* and the shifted-grid planner are, below the start's key. */
 enum { UFM_ALGO_FD = 0, UFM_ALGO_SG = 1, UFM_ALGO_DFM = 2 };
 
 /* return codes */
@@ -169,8 +173,10 @@ int ufm_check_info(ufm_t *p, uint64_t out[6]);
  * + multiplier x distance to the start; FD impl:166-186, DFM impl:135-155).  *total = how many there are; the first `cap` are
  * stored (cap 0 with NULL buffers just counts).  After a step these all lie at / beyond the start's key (end_condition());
  * WHICH elements they are depends on the order of the expansions there, in the reference as here.  MS-DFM: a cell whose
- * value is within UFM_DFM_RTOL of its RHS counts as consistent (the float fixed point of its operator is not unique; the
- * same bound the planner's values are held to against the oracle, unige-tasi-path-planners_amd/tolerances.py). ---- */
+ * value and RHS are both finite and within UFM_DFM_RTOL of each other counts as consistent (the float fixed point of its operator is
+ * not unique).  The bound is self-derived -- twice the spread of that operator's fixed points as this repository's ORACLE restates it,
+ * the reference holds no MS-DFM fixture: parity unpinned -- and defined in ONE place, unige-tasi-path-planners_amd/tolerances.py
+ * (DFM_RTOL); this macro restates it for C callers and tests/test_capi_symbols.py holds the two equal. ---- */
 #define UFM_DFM_RTOL 2e-6f
 int ufm_read_queue(ufm_t *p, int cap, int32_t *xy, float *g_rhs, int *total);
 
@@ -218,11 +224,12 @@ int ufm_batch_set_heuristic_multiplier(ufm_batch_t *b, float mult);
 int ufm_batch_set_map(ufm_batch_t *b, int i, const uint8_t *host_map, int width, int length);
 int ufm_batch_set_map_device(ufm_batch_t *b, int i, const uint8_t *dev_map, int width, int length);
 int ufm_batch_patch_map(ufm_batch_t *b, int i, const uint8_t *host_patch, int x, int y, int w, int h);
-/* Lifetime of dev_patch: a patch of at most 4096 cells handed to a batch of more than one map is applied by ONE launch for all maps
- * at the next ufm_batch_step (or ufm_batch_read_map / _extract_path / _set_map, whichever comes first), not at the call: the buffer must
- * stay valid and unchanged until that call has returned (bench.py: the receive buffer of the round's broadcast, reused two rounds
- * later).  ufm_batch_set_param(b, "defer_patches", 0) applies every patch at the call, stream-ordered, like ufm_patch_map_device of a
- * single planner and like a batch of one map -- at one launch per patch. */
+/* Lifetime of dev_patch: read at the call, stream-ordered on the engine's stream (ufm_batch_stream), like ufm_patch_map_device of a single
+ * planner: the buffer may be reused as soon as work queued on that stream behind the call may overwrite it.
+ * OPT-IN, ufm_batch_set_param(b, "defer_patches", 1): a patch of at most 4096 cells handed to a batch of more than one map is then applied
+ * by ONE launch for all maps at the next ufm_batch_step (or ufm_batch_read_map / _extract_path / _set_map, whichever comes first), not at
+ * the call -- one launch per round instead of one per map -- and the buffer must stay valid and unchanged until that call has returned
+ * (bench.py turns it on: its patches sit in the receive buffer of the round's broadcast, reused two rounds later). */
 int ufm_batch_patch_map_device(ufm_batch_t *b, int i, const uint8_t *dev_patch, int x, int y, int w, int h);
 int ufm_batch_set_start(ufm_batch_t *b, int i, float x, float y);
 int ufm_batch_set_goal(ufm_batch_t *b, int i, float x, float y);

@@ -23,3 +23,18 @@ def ref_bitmaps():
             name = k[:-5]
             out[name] = (d[k], tuple(float(v) for v in d[name + "_startgoal"]))
     return out
+
+
+def pytest_terminal_summary(terminalreporter):
+    """MS-DFM: the worst deviation from the oracle each test saw, next to the bound it was held to (helpers.note_margin) -- the bound is
+    self-derived (ufm_amd.tolerances), so the margin under it is printed with every run"""
+    try:
+        import helpers
+    except Exception:
+        return
+    if not helpers.MARGINS:
+        return
+    terminalreporter.write_sep("-", "MS-DFM deviations from the oracle (worst per test; bound = what the test asserts)")
+    for test, m in sorted(helpers.MARGINS.items()):
+        terminalreporter.write_line("%-70s worst rel %.3g (%d ulp), bound %.1e, %d of %d values differ, %d comparisons" % (
+            test[:70], m["rel"], m["ulp"], m["bound"], m["differing"], m["n"], m["cmp"]))

@@ -15,6 +15,35 @@ def rtol_for(algo):
     return DFM_RTOL if algo in (2, "DFM") else FIELD_RTOL
 
 
+# MS-DFM comparisons: the worst deviation each test saw and the bound it was held to, printed in the terminal summary (conftest.py) so that
+# the margin under the self-derived DFM_RTOL is on record with every run
+MARGINS = {}
+
+
+def note_margin(what, worst_rel, worst_ulp, bound, differing, n):
+    import os
+    test = os.environ.get("PYTEST_CURRENT_TEST", "?").split(" ")[0].split("::")[-1]
+    m = MARGINS.setdefault(test, {"rel": 0.0, "ulp": 0, "bound": bound, "differing": 0, "n": 0, "cmp": 0})
+    m["rel"] = max(m["rel"], float(worst_rel)); m["ulp"] = max(m["ulp"], int(worst_ulp)); m["bound"] = max(m["bound"], bound)
+    m["differing"] += int(differing); m["n"] += int(n); m["cmp"] += 1
+
+
+def dfm_close(got, want, rtol=None, what=""):
+    """MS-DFM values against the oracle's (arrays of the same shape, `want` finite): |got - want| <= rtol * want (default DFM_RTOL); the
+    worst deviation is noted for the terminal summary (note_margin)"""
+    rtol = DFM_RTOL if rtol is None else rtol
+    got, want = np.asarray(got, np.float32).ravel(), np.asarray(want, np.float32).ravel()
+    if got.size == 0:
+        return True
+    if not np.isfinite(got).all():
+        note_margin(what, np.inf, 0, rtol, int((got != want).sum()), got.size)
+        return False
+    err = np.abs(got.astype(np.float64) - want) / np.maximum(want.astype(np.float64), 1e-30)
+    diff = got != want
+    note_margin(what, err.max(), ulp_diff(got[diff], want[diff]).max() if diff.any() else 0, rtol, int(diff.sum()), got.size)
+    return bool(err.max() <= rtol)
+
+
 def make_pair(algo, opt_lvl, cost, start, goal, thr=1.0, heuristic=False, hm=1.0):
     """Configure an oracle planner and a HIP planner the way the reference's
     demo drivers do (Tests/Planners/FDSTAR/main.cpp:82-88)."""
@@ -37,7 +66,7 @@ def ulp_diff(a, b):
     return np.abs(ia - ib)
 
 
-def check_parity(o, g, what="", below_start_key=False):
+def check_parity(o, g, what="", below_start_key=False, rtol=None):
     """Compare the HIP field with the oracle on the set of elements whose value
     the reference guarantees final (consistent and not beyond the queue top).
     Target: bit-equal (FD / SG are asserted bit-equal by the callers).  Acceptance bound: FIELD_RTOL /
@@ -55,9 +84,13 @@ def check_parity(o, g, what="", below_start_key=False):
     if nbad:
         ud = ulp_diff(a, b)
         rel = np.abs(a.astype(np.float64) - b) / np.maximum(b, 1e-30)
-        rtol = rtol_for(o.algo)
+        rtol = rtol_for(o.algo) if rtol is None else rtol
+        if o.algo == 2:
+            note_margin(what, rel.max(), ud.max(), rtol, nbad, n)
         assert (ud <= 2).all() or (rel <= rtol).all(), "%s: max ulp %d, max rel %.3g over %d/%d differing" % (
             what, int(ud.max()), float(rel.max()), nbad, n)
+    elif o.algo == 2:
+        note_margin(what, 0.0, 0, rtol_for(o.algo) if rtol is None else rtol, 0, n)
     # RHS view: equals G at the fixed point; must agree with the oracle's RHS wherever that is final
     assert np.array_equal(grhs[mask], gg[mask])
     # the engine's redundant copies (neighbour rings, cost windows) agree with their originals
@@ -97,11 +130,20 @@ class DeviceBytes:
         hip = DeviceBytes._hip
         arr = np.ascontiguousarray(arr)
         self.ptr = C.c_void_p()
+        self.nbytes = arr.nbytes
         assert hip.hipMalloc(C.byref(self.ptr), C.c_size_t(max(1, arr.nbytes))) == 0
         assert hip.hipMemcpy(self.ptr, C.c_void_p(arr.ctypes.data), C.c_size_t(arr.nbytes), 1) == 0     # hipMemcpyHostToDevice, synchronous
 
     def data_ptr(self):
         return self.ptr.value
+
+    def overwrite(self, arr):
+        """new contents, once everything queued on the device so far has run (hipDeviceSynchronize, then a synchronous copy)"""
+        import ctypes as C
+        arr = np.ascontiguousarray(arr)
+        assert arr.nbytes <= self.nbytes
+        assert DeviceBytes._hip.hipDeviceSynchronize() == 0
+        assert DeviceBytes._hip.hipMemcpy(self.ptr, C.c_void_p(arr.ctypes.data), C.c_size_t(arr.nbytes), 1) == 0
 
     def free(self):
         if self.ptr:

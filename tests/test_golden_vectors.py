@@ -11,7 +11,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
 import make_oracle_vectors as gen   # noqa: E402
 import ufm_amd                      # noqa: E402
-from helpers import DFM_RTOL        # noqa: E402
+from helpers import DFM_RTOL, dfm_close        # noqa: E402
 
 VEC = np.load(os.path.join(ROOT, "tests", "golden", "oracle_vectors.npz"))
 
@@ -49,7 +49,7 @@ def test_engine_matches_committed_vectors(algo, lvl, heur):
         got, want = g.g()[mask], c["g%d" % i]
         what = "%s-%d%s step %d" % (algo, lvl, "h" if heur else "", i)
         if algo == "DFM":      # tolerance as in helpers.check_parity
-            assert np.all(np.abs(got.astype(np.float64) - want) <= DFM_RTOL * want + 1e-30), what
+            assert dfm_close(got, want), what
         else:
             assert np.array_equal(got, want), what
         if i > 0:

@@ -4,7 +4,7 @@ import pytest
 
 import ufm_amd
 import oracle_py as orc
-from helpers import ALGOS, DFM_RTOL, DeviceBytes, check_parity, make_pair
+from helpers import ALGOS, DFM_RTOL, DeviceBytes, check_parity, dfm_close, make_pair
 
 pytestmark = pytest.mark.gpu
 
@@ -135,7 +135,7 @@ def test_focused_and_full_field_agree_below_the_start_key(algo):
         m = gu < key
         assert m.sum() > 100
         if algo == "DFM":   # tolerance: the float fixed point of the DFM quadratic is not unique
-            assert np.all(np.abs(gf[m].astype(np.float64) - gu[m]) <= DFM_RTOL * gu[m])
+            assert dfm_close(gf[m], gu[m])
         else:
             assert np.array_equal(gf[m], gu[m]), "replan %d: %d differ" % (k, int((gf[m] != gu[m]).sum()))
     assert work[0] < work[1]          # focusing must save work
@@ -243,7 +243,7 @@ def test_resident_scheduler_variants(algo, lvl):
                 else:
                     fin = np.isfinite(ref)
                     assert np.array_equal(fin, np.isfinite(f)), v
-                    assert np.all(np.abs(f[fin].astype(np.float64) - ref[fin]) <= DFM_RTOL * ref[fin] + 1e-30), v
+                    assert dfm_close(f[fin], ref[fin]), v
             p.close()
 
 
@@ -308,7 +308,7 @@ def test_batch_of_independent_maps():
         m = o.trusted_mask(below_start_key=True)   # what a planner honouring end_condition must have finalised
         a, ref = b.read_field(i)[m], o.g()[m]
         assert m.sum() > 10000
-        assert np.all(np.abs(a.astype(np.float64) - ref) <= DFM_RTOL * ref)
+        assert dfm_close(a, ref)
     # patch two of the maps, leave the others alone
     for i in (1, 3):
         patch = np.full((9, 9), 3 + i, dtype=np.uint8)
@@ -319,8 +319,7 @@ def test_batch_of_independent_maps():
     for i, o in enumerate(oracles):
         m = o.trusted_mask(below_start_key=True)
         a, ref = b.read_field(i)[m], o.g()[m]
-        err = np.abs(a.astype(np.float64) - ref)
-        assert np.all(err <= DFM_RTOL * ref), (i, float(err.max()), int(m.sum()))
+        assert dfm_close(a, ref), (i, int(m.sum()))
     assert b.check_layout() == (0, 0)
     b.close()
 
@@ -510,7 +509,7 @@ def test_replan_submission_variants_agree(algo, lvl):
                 r0 = results[0][0]
                 fin = np.isfinite(r0)
                 assert np.array_equal(fin, np.isfinite(g))
-                assert np.all(np.abs(g[fin].astype(np.float64) - r0[fin]) <= DFM_RTOL * r0[fin] + 1e-30)
+                assert dfm_close(g[fin], r0[fin])
     # focused mode (the last loop): against the oracle, below the start's key
     o = __import__("oracle_py").OraclePlanner(ALGOS[algo], lvl, False)
     o.reset(); o.set_occupancy_threshold(1); o.set_map(cost); o.set_start(*start); o.set_goal(*goal)
@@ -530,7 +529,7 @@ def test_replan_submission_variants_agree(algo, lvl):
     for g, log, m in results:
         a, b = g[mask], og[mask]
         if algo == "DFM":
-            assert np.all(np.abs(a.astype(np.float64) - b) <= DFM_RTOL * b + 1e-30)
+            assert dfm_close(a, b)
         else:
             assert np.array_equal(a, b)
 
@@ -730,7 +729,7 @@ def test_config4_batch_of_8_maps_2048_dfm():
             assert int(mask.sum()) > least
             a, ref = b.read_field(m)[mask], o.g()[mask]
             err = np.abs(a.astype(np.float64) - ref)
-            assert np.all(err <= DFM_RTOL * ref), "%s map %d: max rel %.3g" % (what, m, float((err / ref.clip(1)).max()))
+            assert dfm_close(a, ref), "%s map %d: max rel %.3g" % (what, m, float((err / ref.clip(1)).max()))
             worst = max(worst, float((err / ref.clip(1)).max()))
         return worst
     against_oracle("plan", 3_000_000)
@@ -941,11 +940,14 @@ def test_absurd_map_size_fails_cleanly_and_the_handle_survives():
     g.close()
 
 
-def test_batch_device_inputs_and_sharded_handle():
+@pytest.mark.parametrize("defer", [0, 1])
+def test_batch_device_inputs_and_sharded_handle(defer):
     """ufm_batch_set_map_device / ufm_batch_patch_map_device (HBM pointers, e.g. a buffer an RCCL broadcast
     filled) and ufm_batch_create_sharded (here: two engines on the one device of the box, devices = [0, 0]; on a
     node each shard gets its own GPU and ufm_batch_step advances them side by side) give the fields of a
-    one-engine batch fed from host memory, bit for bit (FD, full-field mode)."""
+    one-engine batch fed from host memory, bit for bit (FD, full-field mode).
+    defer = 0 (the default): a patch is read at the call, stream-ordered -- its buffer is overwritten here before the step.
+    defer = 1 (opt-in "defer_patches": one apply launch per round; the buffers stay untouched until the step has returned)."""
     n, size = 4, 160
     costs = [ufm_amd.synth.cost_map(50 + i, size, size) for i in range(n)]
     start, goal = ufm_amd.synth.start_goal(size, size)
@@ -956,6 +958,7 @@ def test_batch_device_inputs_and_sharded_handle():
     d_costs = [DeviceBytes(c) for c in costs]
     for p in (a, b):
         p.set_param("focused", 0); p.set_occupancy_threshold(1)
+    b.set_param("defer_patches", defer)
     for i in range(n):
         a.set_map(i, costs[i]); b.set_map_device(i, d_costs[i].data_ptr(), size, size)
         for p in (a, b):
@@ -974,6 +977,9 @@ def test_batch_device_inputs_and_sharded_handle():
                 a.patch_map(i, p2, top + 5, left + 7); b.patch_map_device(i, dp2.data_ptr(), top + 5, left + 7, 17, 20)
             for p in (a, b):
                 p.set_start(i, *s)
+        if not defer:                  # the ABI's lifetime: the call has read (queued the read of) the buffer -- what happens to it afterwards is the caller's business
+            for dp in keep:
+                dp.overwrite(np.full(dp.nbytes, 77, np.uint8))
         if r == 2:                     # a read of the raster between patch and step sees the patch
             assert np.array_equal(a.read_map(1, size, size), b.read_map(1, size, size))
         assert a.step() == 0 and b.step() == 0

@@ -65,6 +65,19 @@ def test_queue_view_invariants(algo, lvl, heur):
         if total:
             slack = DFM_RTOL * skey if algo == "DFM" else 0.0
             assert k1.min() >= skey - slack, "%s: an element with key %r waits below the start's key %r" % (what, float(k1.min()), skey)
+        if algo == "DFM":
+            # never-expanded frontier cells (G = +inf, RHS finite) are the bulk of the reference's queue after a focused step: they must be in the
+            # view (round 3 dropped them: the tolerance test `|g - r| <= rtol * |g|` read inf <= inf), and every cell the oracle leaves unexpanded
+            # between finalised neighbours is one of them wherever the engine has not given it a value either
+            inf_entries = np.isinf(qg) & np.isfinite(qrhs)
+            assert int(inf_entries.sum()) > 0, what
+            tm = o.trusted_mask(below_start_key=True)
+            allnb = np.zeros_like(tm)
+            allnb[1:-1, 1:-1] = np.logical_and.reduce([tm[1 + dx:tm.shape[0] - 1 + dx, 1 + dy:tm.shape[1] - 1 + dy] for dx in (-1, 0, 1) for dy in (-1, 0, 1) if dx or dy])
+            need = np.isinf(og) & np.isfinite(orhs) & allnb & np.isinf(field)
+            inview = set(map(tuple, xy[np.isinf(qg)].tolist()))
+            missing = [tuple(c) for c in np.argwhere(need).tolist() if tuple(c) not in inview]
+            assert not missing, (what, missing[:5], int(need.sum()))
         # a capped read: the same count, the first `cap` entries
         if total > 3:
             xy3, g3, r3, t3 = g.read_queue(cap=3)

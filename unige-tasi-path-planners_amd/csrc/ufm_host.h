@@ -145,11 +145,13 @@ struct Engine {
     int read_bounds(float *bmax);
     int step(ufm_stats *out);
     int patch(int m, const uint8_t *dev_patch, int x, int y, int w, int h, bool may_defer = false);
-    // Small patches handed over as device pointers are held back until something needs them applied (the next step, a read
-    // of the raster, a path extraction): the caller keeps such a buffer valid until the next step() has returned anyway.
+    // OPT-IN (ufm_batch_set_param "defer_patches", 1; round 4: it was the default, which silently extended the lifetime the ABI asks of
+    // a patch buffer): small patches handed to a batch as device pointers are held back until something needs them applied (the next
+    // step, a read of the raster, a path extraction) and applied by ONE launch -- the caller then keeps each buffer valid and unchanged
+    // until that call has returned.  Off: every patch is applied at the call, stream-ordered, like a single planner's.
     struct DeferredPatch { int m, x, y, w, h; const uint8_t *ptr; };
     std::vector<DeferredPatch> deferred;
-    bool defer_patches = true;
+    bool defer_patches = false;
     int flush_deferred();
 };
 

@@ -539,7 +539,9 @@ __global__ void k_queue_scan(PathField F, int lvl, int gx, int gy, int cap, int3
         // MS-DFM: the float fixed point of the upwind quadratic is not unique -- the field is a fixed point of the
         // relaxation's evaluation of the candidates, min_rhs<1>() as restated here may round the last bits the other way: within the
         // planner's tolerance (UFM_DFM_RTOL, include/ufm.h) a cell counts as consistent
-        if (F.cells && fabsf(g - r) <= UFM_DFM_RTOL * fmaxf(fabsf(g), 1.0f)) continue;
+        // (both values finite: with G = +inf the bound is +inf too and `inf <= inf` would drop every never-expanded frontier cell -- the bulk of the
+        //  reference's queue after a focused step)
+        if (F.cells && g < INFINITY && r < INFINITY && fabsf(g - r) <= UFM_DFM_RTOL * fmaxf(fabsf(g), 1.0f)) continue;
         const unsigned int i = atomicAdd(count, 1u);
         if (i < (unsigned int)cap) { xy[2 * i] = x; xy[2 * i + 1] = y; gr[2 * i] = g; gr[2 * i + 1] = r; }
     }
