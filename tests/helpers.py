@@ -11,8 +11,13 @@ FIELD_RTOL = ufm_amd.tolerances.FIELD_RTOL
 DFM_RTOL = ufm_amd.tolerances.DFM_RTOL
 
 
-def rtol_for(algo):
-    return DFM_RTOL if algo in (2, "DFM") else FIELD_RTOL
+def rtol_for(algo, n_elements=None):
+    """FD / SG: FIELD_RTOL (and the callers assert bit equality on top).  MS-DFM: SURVEY 8(d)'s 1e-6 (FIELD_RTOL) wherever the measured worst case
+    leaves room -- maps up to 512^2: worst seen 6.5e-7, see the margins table pytest prints --, the self-derived DFM_RTOL = 2e-6 for the larger
+    ones (1024^2: 7.9e-7, 2048^2: 9.4e-7 and 1.02e-6 on config 4's seed-1003 map; results vary from run to run by as much)."""
+    if algo not in (2, "DFM"):
+        return FIELD_RTOL
+    return FIELD_RTOL if (n_elements is not None and n_elements <= 512 * 512) else DFM_RTOL
 
 
 # MS-DFM comparisons: the worst deviation each test saw and the bound it was held to, printed in the terminal summary (conftest.py) so that
@@ -84,13 +89,13 @@ def check_parity(o, g, what="", below_start_key=False, rtol=None):
     if nbad:
         ud = ulp_diff(a, b)
         rel = np.abs(a.astype(np.float64) - b) / np.maximum(b, 1e-30)
-        rtol = rtol_for(o.algo) if rtol is None else rtol
+        rtol = rtol_for(o.algo, og.size) if rtol is None else rtol
         if o.algo == 2:
             note_margin(what, rel.max(), ud.max(), rtol, nbad, n)
         assert (ud <= 2).all() or (rel <= rtol).all(), "%s: max ulp %d, max rel %.3g over %d/%d differing" % (
             what, int(ud.max()), float(rel.max()), nbad, n)
     elif o.algo == 2:
-        note_margin(what, 0.0, 0, rtol_for(o.algo) if rtol is None else rtol, 0, n)
+        note_margin(what, 0.0, 0, rtol_for(o.algo, og.size) if rtol is None else rtol, 0, n)
     # RHS view: equals G at the fixed point; must agree with the oracle's RHS wherever that is final
     assert np.array_equal(grhs[mask], gg[mask])
     # the engine's redundant copies (neighbour rings, cost windows) agree with their originals
