@@ -344,9 +344,33 @@ def run_rank(args, planner_factory=None, factory_label=None):
             else:
                 p.set_map_device(d_cost.data_ptr(), size, size)
 
+        # N = 1 (no process group): the patches are handed over FROM HOST MEMORY through ufm_patch_map inside the timed region -- SURVEY 8(d)'s
+        # metric includes the patch upload -- and that episode is `value`; the device-resident form below (the receive buffer of a broadcast:
+        # the N > 1 data path) is timed as a second leg and reported as `value_device_inputs`.
+        h_patches = np.ascontiguousarray(np.stack([s[4] for s in script])) if script else np.zeros((1, psz, psz), np.uint8)
+        h_ptrs = [h_patches.ctypes.data + i * psz * psz for i in range(len(script))]
+
+        class HostPatches:
+            broadcasts = 0
+
+            def fetch(self, i):
+                return i
+
+            def close(self):
+                pass
+
+        def apply_patch_host(p, i, top, left):
+            p.patch_map_host(h_ptrs[i], top, left, psz, psz)
+
+        legs = {"device": (stream, apply_patch)}
+        if dist is None and not rehearsal:
+            legs["host"] = (HostPatches(), apply_patch_host)
+        leg = ["host" if "host" in legs else "device"]
+
         def run_one():
-            return ep.run_episode(planner, set_map=set_map, start=start, goal=goal, script=meta, stream=stream,
-                                  apply_patch=apply_patch, read_stats=step_stats, phases=phases)
+            st_, ap_ = legs[leg[0]]
+            return ep.run_episode(planner, set_map=set_map, start=start, goal=goal, script=meta, stream=st_,
+                                  apply_patch=ap_, read_stats=step_stats, phases=phases)
 
         def self_check():
             # every rank's raster must now be its own map with all the broadcast patches applied -- a collective
@@ -438,6 +462,8 @@ def run_rank(args, planner_factory=None, factory_label=None):
             return out
 
     phases = {}         # host wall seconds of the episodes' parts, summed over warm-up and timed episodes (run_episode)
+    if M != 0:
+        legs, leg = {"device": None}, ["device"]
 
     def barrier():
         if not rehearsal:
@@ -454,6 +480,16 @@ def run_rank(args, planner_factory=None, factory_label=None):
     for _ in range(args.warmup):
         run_warm()
     dt, per_step = ep.timed_episodes(run_one, args.steps, 0, barrier)
+    device_leg = None
+    if leg[0] == "host":            # the second leg: the same episodes with the patches resident in HBM (ufm_patch_map_device)
+        phases_host = dict(phases)
+        leg[0] = "device"
+        run_warm()
+        dt_d, per_step_d = ep.timed_episodes(run_one, args.steps, 0, barrier)
+        cells_d = sum(stats_dict(sn)["cells"] for snaps in per_step_d for sn in snaps)
+        device_leg = {"dt": dt_d, "cells": cells_d, "phases": dict(phases)}
+        phases.clear(); phases.update(phases_host)
+        leg[0] = "host"
     last_snapshot = None
     if not rehearsal:       # the snapshots of every step of an episode -> one summed dict per episode
         summed = []
@@ -509,8 +545,11 @@ def run_rank(args, planner_factory=None, factory_label=None):
             "dtype": "f32",
             "data": "synthetic",
             "config": {
-                "workload": "%s, %dx%d cost map (seed %d generator, SURVEY 8d), full plan + %d 31x31 patches with moving start, %s" % (
-                    ALGO_LABEL[args.algo], size, size, seed, n_rounds, maps_desc),
+                "workload": "%s, %dx%d cost map (seed %d generator, SURVEY 8d), full plan + %d 31x31 patches with moving start, %s; %s" % (
+                    ALGO_LABEL[args.algo], size, size, seed, n_rounds, maps_desc,
+                    "patches handed over from host memory inside the timed region (ufm_patch_map)" if device_leg is not None else
+                    "patches resident in HBM (ufm_patch_map_device: the receive buffer of the patch broadcast)"),
+                "patch_inputs": "host" if device_leg is not None else "device",
                 "algo": args.algo, "size": size, "patches": n_rounds, "heuristic_keys": bool(args.heuristic),
                 "maps_per_gpu": n_local, "maps_total": n_local * world,
                 # one broadcast per replan (round) per rank, warm-up episodes included; 0 without a process group
@@ -529,6 +568,10 @@ def run_rank(args, planner_factory=None, factory_label=None):
                          "plan_cells": (cells - reg[4]) / steps_ if not rehearsal else None,
                          "replans_cells": reg[4] / steps_ if not rehearsal else None,
                          "note": "host wall per episode on rank 0; cells of the replans = those of the steps the block kernel ran (all of them here)"}
+        if device_leg is not None:
+            out["value_device_inputs"] = device_leg["cells"] / device_leg["dt"]
+            out["ms_per_step_device_inputs"] = 1e3 * device_leg["dt"] / steps_
+            out["phases"]["replans_ms_device_inputs"] = 1e3 * device_leg["phases"].get("replans", 0.0) / steps_
         if rehearsal:
             out["rehearsal"] = "CPU stand-in planner %s over %s: control flow only, not a measurement" % (factory_label, args.backend)
         lvis, llaunch, lkms, ltimed = low

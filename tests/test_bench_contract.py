@@ -32,6 +32,11 @@ def test_bench_line_single_gpu():
         assert k in d, k
     assert d["n_gpus"] == 1 and d["unit"] == "cells/s" and d["scaling"] == "weak" and d["dtype"] == "f32"
     assert d["value"] > 0 and d["vs_baseline"] is None
+    # N = 1: `value` is SURVEY 8(d)'s metric -- the patches come from host memory through ufm_patch_map inside the timed region --, the
+    # device-resident form (the N > 1 data path) is reported next to it
+    assert d["config"]["patch_inputs"] == "host" and d["value_device_inputs"] > 0 and d["ms_per_step_device_inputs"] > 0
+    assert d["phases"]["replans_ms_device_inputs"] > 0
+    assert 0.5 < d["value_device_inputs"] / d["value"] < 2.0
     r = d["roofline"]
     assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12 and r["avg_launch_us"] > 0 and r["timed_launches"] > 0
@@ -52,6 +57,7 @@ def test_bench_line_single_gpu():
 def test_bench_line_with_collectives_one_rank():
     d = _run("--force-dist", "--no-cpu-baseline")        # RCCL: init, broadcast per replan (one ahead), all_reduce, barrier
     assert d["n_gpus"] == 1 and d["value"] > 0
+    assert d["config"]["patch_inputs"] == "device" and "value_device_inputs" not in d      # with a process group the patches arrive in HBM
     d = _run("--force-dist", "--no-pipeline", "--no-cpu-baseline")
     assert d["value"] > 0
 

@@ -137,3 +137,65 @@ def test_start_walled_in_by_a_patch_and_freed_by_the_next(algo, lvl):
     step_and_check(o, g, "freed again")
     assert np.isfinite(g.g()[20, 22])
     g.close()
+
+
+def test_host_patches_held_for_the_block_kernel():
+    """ufm_patch_map of a small patch (single planner) is held in pinned memory and applied by the replan's block kernel itself (round 4:
+    no staging copy, no patch kernel).  What a caller can observe must not change -- held against the same engine with "lazy_patches" 0
+    (every patch uploaded and applied at the call), bit for bit: the caller's buffer is free when the call returns (overwritten here), a read
+    of the raster between patch and step sees the patch, two patches before one step both count and keep their order where they overlap
+    (the engine accumulates them; the reference keeps the last change list only, Graph.cpp:37), host and device patches mix, and a step
+    that does not consume the patches (no new start) leaves them applied to the raster but not propagated (ReplannerBase.h:43-75).
+    (Against the ORACLE the held patches are covered by every parity test of a single planner: they all hand their patches over from host memory.)"""
+    from helpers import DeviceBytes
+    size = 192
+    cost = ufm_amd.synth.cost_map(31, size, size)
+    start, goal = ufm_amd.synth.start_goal(size, size)
+    ga, gb = ufm_amd.Planner(ufm_amd.ALGO_FD, 1, False), ufm_amd.Planner(ufm_amd.ALGO_FD, 1, False)
+    ga.set_param("lazy_patches", 1); gb.set_param("lazy_patches", 0)
+    for p in (ga, gb):
+        p.reset(); p.set_occupancy_threshold(1); p.set_map(cost); p.set_start(*start); p.set_goal(*goal)
+        assert p.step() == 0
+    expect = cost.copy()
+    rng = np.random.default_rng(5)
+    keep = []
+    for k in range(9):
+        top, left = int(rng.integers(20, size - 60)), int(rng.integers(20, size - 60))
+        patch = rng.integers(1, 201, (31, 31)).astype(np.uint8)
+        for p in (ga, gb):
+            buf = patch.copy()
+            p.patch_map(buf, top, left)
+            buf[:] = 7                                            # the caller's buffer is its own again
+        expect[top:top + 31, left:left + 31] = patch
+        if k % 3 == 1:                                            # a second, overlapping patch before the step
+            p2 = rng.integers(1, 201, (20, 17)).astype(np.uint8)
+            for p in (ga, gb):
+                p.patch_map(p2.copy(), top + 5, left + 7)
+            expect[top + 5:top + 25, left + 7:left + 24] = p2
+        if k == 2:                                                # a device patch behind a held host patch
+            p3 = rng.integers(1, 201, (9, 9)).astype(np.uint8)
+            d3 = DeviceBytes(p3); keep.append(d3)
+            for p in (ga, gb):
+                p.patch_map_device(d3.data_ptr(), top + 1, left + 1, 9, 9)
+            expect[top + 1:top + 10, left + 1:left + 10] = p3
+        if k == 4:                                                # the raster is read before the step
+            assert np.array_equal(ga.read_map(size, size), expect)
+        if k == 5:                                                # a step without a new start: patches applied, not consumed
+            for p in (ga, gb):
+                assert p.step() == 0
+            assert np.array_equal(ga.read_map(size, size), expect)
+        cur = (float(8 + 3 * k), float(8 + 2 * k))
+        for p in (ga, gb):
+            p.set_start(*cur)
+            assert p.step() == 0
+        what = "step %d" % k
+        assert ga.num_nodes_updated == gb.num_nodes_updated, (what, ga.num_nodes_updated, gb.num_nodes_updated)
+        fa, fb = ga.g(), gb.g()
+        key = min(float(fa[int(cur[0]) + i, int(cur[1]) + j]) for i in (0, 1) for j in (0, 1))
+        m = np.isfinite(fb) & (fb < key)
+        assert m.sum() > 1000 and np.array_equal(fa[m], fb[m]), what
+        assert np.array_equal(ga.read_map(size, size), expect) and np.array_equal(gb.read_map(size, size), expect), what
+        assert ga.check_layout() == (0, 0) and ga.check_info()[1:4] == (0, 0, 0), what
+    if hasattr(ga.stats, "region_replans"):
+        assert ga.stats.region_replans >= 6                   # the held patches did go through the block kernel
+    ga.close(); gb.close()

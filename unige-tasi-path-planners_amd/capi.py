@@ -216,6 +216,10 @@ class Planner:
     def patch_map_device(self, dev_ptr, x, y, w, h):
         _chk(self.L.ufm_patch_map_device(self.h, dev_ptr, int(x), int(y), int(w), int(h)), "ufm_patch_map_device")
 
+    def patch_map_host(self, host_ptr, x, y, w, h):
+        """ufm_patch_map with the address of a host buffer (a caller that keeps its patches in one array: no numpy view per call)"""
+        _chk(self.L.ufm_patch_map(self.h, host_ptr, int(x), int(y), int(w), int(h)), "ufm_patch_map")
+
     def set_start(self, x, y):
         _chk(self.L.ufm_set_start(self.h, float(x), float(y)), "ufm_set_start")
 

@@ -179,6 +179,32 @@ __global__ void k_own_import(DevParams P, int k) {
         P.ctr->own_abort = 0;
     }
 }
+// Round 4 experiment (P.dag_on): from the arrival estimates dag_a, per tile the threshold below which a neighbour counts as "clearly before it"
+// -- halfway (kappa) between the tile's own estimate and its earliest neighbour's -- and the number of such neighbours (dag_left, in the owners' layout).
+// A tile without an estimate (+inf / NaN: the estimate does not reach it) waits for nobody.
+__global__ void k_dag_setup(DevParams P, float kappa) {
+    for (int gt = blockIdx.x * blockDim.x + threadIdx.x; gt < P.NT; gt += gridDim.x * blockDim.x) {
+        const int m = gt / P.NTm, t = gt - m * P.NTm, tx = t / P.TY, ty = t - tx * P.TY;
+        const float a = P.dag_a[gt];
+        float amin = INFINITY;
+        for (int d = 0; d < 9; ++d) {
+            const int ntx = tx + d / 3 - 1, nty = ty + d % 3 - 1;
+            if (d == 4 || ntx < 0 || nty < 0 || ntx >= P.TX || nty >= P.TY) continue;
+            amin = fminf(amin, P.dag_a[m * P.NTm + ntx * P.TY + nty]);
+        }
+        const float thr = (a < INFINITY && amin < a) ? a - kappa * (a - amin) : -INFINITY;
+        int n = 0;
+        for (int d = 0; d < 9; ++d) {
+            const int ntx = tx + d / 3 - 1, nty = ty + d % 3 - 1;
+            if (d == 4 || ntx < 0 || nty < 0 || ntx >= P.TX || nty >= P.TY) continue;
+            n += P.dag_a[m * P.NTm + ntx * P.TY + nty] < thr ? 1 : 0;
+        }
+        P.dag_thr[gt] = thr;
+        int o, s_;
+        own_locate(P, gt, o, s_);
+        P.dag_left[(size_t)o * P.own_slots + s_] = n;
+    }
+}
 // ... and this one gives what it left queued -- tiles beyond the start's key; everything, had it run into its time
 // limit -- back to the launch chain as the list of launch k1 = k + 1, and leaves all words empty.
 __global__ void k_own_export(DevParams P, int k1) {

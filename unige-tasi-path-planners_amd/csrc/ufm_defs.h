@@ -190,6 +190,14 @@ struct DevParams {
     int *own_lock;              // [OWN_NW][own_slots] 1 while the tile is being visited: whoever takes a tile (its owner, or an idle workgroup helping
                                 // out) needs both the queue word AND this lock -- an activation that lands during a visit re-queues the tile at once
     int *own_min;               // [OWN_NW] smallest priority each owner holds (queued or in flight): a hint for the ordering band, not exact
+    // Round 4 experiment: first visits gated by an approximate arrival order.  dag_a[tile] = estimate of when the front reaches
+    // the tile (any monotone proxy); a tile's FIRST visit waits until every neighbour that the estimate puts clearly before it (dag_a < dag_thr
+    // of the tile) has had its first visit: dag_left counts those neighbours down (grouped like own_prio).  Later visits are not gated.
+    float *dag_a;               // [NT]
+    float *dag_thr;             // [NT]
+    int *dag_left;              // [OWN_NW][own_slots]
+    int dag_on;                 // 0: off (ordering band only)
+    int dag_patience;           // looks without an eligible tile after which a workgroup takes a held one anyway (an estimate may name a neighbour that never comes)
     unsigned long long own_limit;   // wall-clock ticks (100 MHz) after which the resident kernel hands back to the launch chain
     int own_flags;              // diagnostics: 1 = no tile taken ahead (every visit starts with a fresh look at the queue)
     int own_slots, own_sx, own_sy;  // words per owner = nmaps * own_sx * own_sy; blocks of 16 x (1 << own_ys) tiles per map side

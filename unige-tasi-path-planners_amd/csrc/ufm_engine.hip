@@ -119,6 +119,15 @@ int ufm_debug_lmax(ufm_t *p, int32_t *out, int n) {      // diagnostics array of
     hipStreamSynchronize(p->e->stream);
     return hipMemcpy(out, p->e->P.lmax, sizeof(int) * n, hipMemcpyDeviceToHost) == hipSuccess ? UFM_OK : UFM_ERR_HIP_BASE;
 }
+// round 4 experiment: an arrival estimate per tile ([TX][TY] floats of map 0, +inf = no estimate) for the gated first visits of the resident kernel
+// (ufm_set_param "dag", 1); tools/dag_probe.py hands in the true first-arrival values of an earlier plan.  Not part of include/ufm.h.
+int ufm_debug_set_tile_order(ufm_t *p, const float *a, int n) {
+    if (!p || !p->e->allocated || !a || n != p->e->P.NT) return UFM_ERR_INVALID;
+    hipStreamSynchronize(p->e->stream);
+    if (hipMemcpy(p->e->P.dag_a, a, sizeof(float) * (size_t)n, hipMemcpyHostToDevice) != hipSuccess) return UFM_ERR_HIP_BASE;
+    p->e->dag_have = true;
+    return UFM_OK;
+}
 int ufm_tile_edge(void) { return T; }
 #ifdef UFM_STRICT_FENCES
 const char *ufm_version(void) { return "ufm-gfx950 0.1 (block-FIM, strict-fence checking build)"; }
@@ -271,6 +280,10 @@ static int engine_set_param(Engine *e, const char *name, double value) {
     else if (!std::strcmp(name, "profile_stride")) e->profile_stride = value < 1 ? 1 : (int)value;
     else if (!std::strcmp(name, "focused")) e->focused = value != 0.0;
     else if (!std::strcmp(name, "start_cell_floor")) e->start_cell_floor = value != 0.0;
+    else if (!std::strcmp(name, "lazy_patches")) { if (e->allocated) { int rc = e->flush_deferred(); if (rc != UFM_OK) return rc; } e->lazy_patches = value != 0; }
+    else if (!std::strcmp(name, "dag")) e->dag_mode = (int)value;
+    else if (!std::strcmp(name, "dag_kappa")) e->dag_kappa = (float)value;
+    else if (!std::strcmp(name, "dag_patience")) e->dag_patience = value < 1 ? 1 : (int)value;
     else if (!std::strcmp(name, "dynamic")) e->dynamic_mode = value != 0.0;
     else return UFM_ERR_INVALID;
     return UFM_OK;

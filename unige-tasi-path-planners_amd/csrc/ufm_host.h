@@ -55,6 +55,10 @@ struct Engine {
     int owned_flags = 0;             // resident kernel, diagnostics and variants.  1: no tile taken ahead; 2: no early hand-off (FD / SG); 4: early hand-off once per patch and visit;
                                      // 8: early hand-off waits for its stores inside the sweep loop; 16: no in-visit halo refresh; 32: idle workgroups do not help out
     int owned_waves = 0;             // waves per tile visit of the resident kernel: 16 (256 workgroups), 8 (512), 0 = by the size of the job
+    int dag_mode = 0;                // round 4 experiment: first visits gated by an arrival estimate.  0 off; 1: the estimate handed in through ufm_debug_set_tile_order
+    bool dag_have = false;           // ... an estimate is in P.dag_a
+    float dag_kappa = 0.5f;          // ... a neighbour counts as clearly earlier below own estimate - kappa x (own - earliest neighbour's)
+    int dag_patience = 16;           // ... looks without an eligible tile before a workgroup takes a held one anyway
     bool use_region = true;          // replans: one workgroup runs both phases in LDS on the block around the patch (ufm_region.h);
                                      // the launch chain only takes over when work is left outside the block
     int region_ahead = 2;            // block placement: tiles kept between the patches' centre and the block's goal-side edge
@@ -153,6 +157,24 @@ struct Engine {
     std::vector<DeferredPatch> deferred;
     bool defer_patches = false;
     int flush_deferred();
+    int flush_deferred_only();
+    // A small patch of a SINGLE planner handed over from HOST memory (ufm_patch_map) is not uploaded and applied at the call: its bytes are
+    // copied into a slot of host-coherent pinned memory (the caller's buffer is free again when the call returns, as before) and the replan's
+    // block kernel reads them from there and does Graph::update + the seeding itself (RegionJob::psrc) -- no staging copy, no stream
+    // synchronisation, no patch kernel in front of the replan.  Whatever else needs the raster first (a read of the map, a path extraction,
+    // another kind of patch, a step that does not go through the block kernel) applies the held patches the ordinary way: flush_lazy().
+    static constexpr int LAZY_SLOTS = 4;                  // = the most rectangles a block-kernel job takes
+    struct LazyPatch { int m, x, y, w, h, slot; };
+    std::vector<LazyPatch> lazy;
+    uint8_t *h_lazy = nullptr;       // LAZY_SLOTS x 4096 bytes, pinned + mapped
+    int lazy_next = 0;               // slot after the last one handed out
+    bool lazy_dirty[LAZY_SLOTS] = {false, false, false, false};   // a kernel queued on the stream may still read the slot
+    bool lazy_patches = true;
+    int patch_lazy(int m, const uint8_t *host_patch, int x, int y, int w, int h, bool *taken);
+    int flush_lazy();
+    int ensure_pmask(size_t n);
+    bool region_fits(const int (*rects)[5], int nrect, int m, int *tx0, int *ntx, int *ty0, int *nty) const;
+    bool lazy_region_ok() const;
 };
 
 void Engine::release() {
@@ -163,7 +185,7 @@ void Engine::release() {
     std::memset(&graph_sig, 0, sizeof(graph_sig));
     void *ptrs[] = {P.G, P.Gprev, P.bp, P.ring, P.cost, P.costT, P.goal, P.cand, P.ready, P.hint, P.rank, P.park, P.pflag, P.pprio,
                     P.queued, P.prio, P.start, P.bnd, P.dyn, P.spos, P.touched, P.fresh, P.tlist, P.sflag, P.slist, P.slist2,
-                    P.mark, P.num_updated, P.consume, P.lmax, P.own_prio, P.own_lock, P.own_min, P.ctr, d_scratch};
+                    P.mark, P.num_updated, P.consume, P.lmax, P.own_prio, P.own_lock, P.own_min, P.dag_a, P.dag_thr, P.dag_left, P.ctr, d_scratch};
     for (void *q : ptrs) if (q) hipFree(q);
     P = DevParams{};                     // every pointer null again: a failed alloc() can be released, and released twice
     d_scratch = nullptr;
@@ -232,6 +254,10 @@ int Engine::alloc(int width, int length) {
     dmalloc(P.own_prio, sizeof(int) * own_words());
     dmalloc(P.own_lock, sizeof(int) * own_words());
     dmalloc(P.own_min, sizeof(int) * OWN_NW);
+    dag_have = false;
+    dmalloc(P.dag_a, sizeof(float) * (size_t)P.NT);
+    dmalloc(P.dag_thr, sizeof(float) * (size_t)P.NT);
+    dmalloc(P.dag_left, sizeof(int) * own_words());
     dmalloc(P.ctr, sizeof(DevCounters));
     dmalloc(d_scratch, sizeof(int) * (4 * nmaps + 16));
     if (rc != UFM_OK) { release(); return rc; }
@@ -456,6 +482,9 @@ int Engine::owned_phase() {
     //  SG 2048^2 7.08 against 6.55, 1024^2 3.40 against 2.84; MS-DFM, whose visits are longer and which has no early hand-off, 2048^2 13.1 against 15.0)
     const bool half = T == 16 && (owned_waves == 8 || (owned_waves == 0 && (nmaps > 1 || P.NTm > (algo == UFM_ALGO_DFM ? 12000 : 50000))));
     own_layout(half ? 5 : 4);
+    P.dag_on = (dag_mode != 0 && dag_have) ? 1 : 0;
+    P.dag_patience = dag_patience;
+    if (P.dag_on) k_dag_setup<<<256, 256, 0, stream>>>(P, dag_kappa);
     k_own_import<<<64, 256, 0, stream>>>(P, k);
     // 16 waves per tile visit, one visit per CU -- or 8 and two: a visit is then ~17 % longer and a CU makes 1.7 x as many.  That pays
     // where there are always more tiles to visit than workgroups (several maps, or a front as long as that of an 8192^2 map); a single
@@ -576,7 +605,11 @@ int Engine::run_phase(int mode, float rbound, uint32_t *launches, float *kernel_
     }
 }
 
-int Engine::flush_deferred() {
+int Engine::flush_deferred() {       // every patch that is being held -- a single planner's host patches, a batch's deferred device patches -- applied
+    { int rc = flush_lazy(); if (rc != UFM_OK) return rc; }
+    return flush_deferred_only();
+}
+int Engine::flush_deferred_only() {
     if (deferred.empty()) return UFM_OK;
     PatchMulti a{};
     a.n = (int)deferred.size();
@@ -592,19 +625,94 @@ int Engine::flush_deferred() {
     return UFM_OK;
 }
 
+int Engine::ensure_pmask(size_t n) {   // room for the masks of PATCH_MULTI small patches, or of one large one
+    const size_t need = std::max((size_t)PATCH_MULTI * 4096, n);
+    if (need > d_pmask_cap) {
+        { int rc = flush_deferred_only(); if (rc != UFM_OK) return rc; }      // (their launch writes the old buffer)
+        if (d_pmask) { HIPCHK(hipStreamSynchronize(stream)); hipFree(d_pmask); d_pmask = nullptr; d_pmask_cap = 0; }
+        HIPCHK(hipMalloc(&d_pmask, need));
+        d_pmask_cap = need;
+    }
+    return UFM_OK;
+}
+// the held host patches, applied the ordinary way (one k_patch_small each, reading the pinned slot), in the order they came
+int Engine::flush_lazy() {
+    if (lazy.empty()) return UFM_OK;
+    { int rc = ensure_pmask(4096); if (rc != UFM_OK) return rc; }
+    for (const LazyPatch &p : lazy) {
+        const uint8_t *src = h_lazy + (size_t)p.slot * 4096;
+        if (algo == UFM_ALGO_DFM) k_patch_small<false><<<1, 1024, 0, stream>>>(P, p.m, src, d_pmask, p.x, p.y, p.w, p.h);
+        else k_patch_small<true><<<1, 1024, 0, stream>>>(P, p.m, src, d_pmask, p.x, p.y, p.w, p.h);
+        lazy_dirty[p.slot] = true;         // (read by a kernel that is only queued: patch_lazy waits for the stream before it writes the slot again)
+    }
+    lazy.clear();
+    HIPCHK(hipGetLastError());
+    return UFM_OK;
+}
+// ufm_patch_map of a small patch, single planner: hold it (see the member's comment); *taken = false: the caller goes the ordinary way
+int Engine::patch_lazy(int m, const uint8_t *host_patch, int x, int y, int w, int h, bool *taken) {
+    *taken = false;
+    if (m < 0 || m >= nmaps || !allocated || !maps[m].have_map) return UFM_ERR_INVALID;
+    if (x < 0 || y < 0 || w <= 0 || h <= 0 || x + h > L || y + w > W) return UFM_ERR_INVALID;   // Graph.cpp:38-41
+    if (!(lazy_patches && nmaps == 1 && use_region && fuse_control && spin_wait && w <= 64 && h <= 64)) return UFM_OK;
+    if ((int)lazy.size() >= LAZY_SLOTS || pending.size() != lazy.size()) return UFM_OK;      // (only behind other held patches: the block kernel applies them in order)
+    if (!h_lazy) HIPCHK(hipHostMalloc(&h_lazy, (size_t)LAZY_SLOTS * 4096, hipHostMallocMapped));
+    // (a slot is free again when the step that consumed its patch has returned -- step() is synchronous -- or when flush_lazy() has run and the
+    //  stream has been waited for; slots are handed out in order, so the one after the last held patch's is the oldest)
+    const int slot = lazy.empty() ? (lazy_next % LAZY_SLOTS) : ((lazy.back().slot + 1) % LAZY_SLOTS);
+    if (lazy_dirty[slot]) { HIPCHK(hipStreamSynchronize(stream)); for (bool &d : lazy_dirty) d = false; }
+    std::memcpy(h_lazy + (size_t)slot * 4096, host_patch, (size_t)w * h);
+    __atomic_thread_fence(__ATOMIC_RELEASE);
+    lazy.push_back({m, x, y, w, h, slot});
+    lazy_next = slot + 1;
+    pending.push_back({m, x, y, w, h});
+    *taken = true;
+    return UFM_OK;
+}
+// the block of the replan kernel around a set of consumed rectangles {map, x, y, w, h}: its goal-side edge `region_ahead` tiles beyond the
+// rectangles' centre, the rest of its extent behind it -- where the elements that lean on the patched cells are; false if they do not fit into one block
+bool Engine::region_fits(const int (*rects)[5], int nrect, int m, int *tx0, int *ntx, int *ty0, int *nty) const {
+    if (nrect <= 0) return false;
+    const bool nodes = algo != UFM_ALGO_DFM;
+    int ex0 = INT32_MAX, ex1 = -1, ey0 = INT32_MAX, ey1 = -1;
+    for (int r = 0; r < nrect; ++r) {
+        const int *qr = rects[r];
+        ex0 = std::min(ex0, qr[1]); ex1 = std::max(ex1, qr[1] + qr[4] - (nodes ? 0 : 1));
+        ey0 = std::min(ey0, qr[2]); ey1 = std::max(ey1, qr[2] + qr[3] - (nodes ? 0 : 1));
+    }
+    auto place = [&](int e0, int e1, int goal_e, int ntiles_map, int *t0, int *nt) {
+        *nt = std::min(std::min(region_tiles, RTMAX), ntiles_map);
+        const int tc = ((e0 + e1) / 2) / T;
+        int lo = (goal_e >= (e0 + e1) / 2) ? tc + region_ahead - *nt + 1 : tc - region_ahead;
+        lo = std::max(0, std::min(lo, ntiles_map - *nt));
+        *t0 = lo;
+        return e0 / T >= lo && e1 / T <= lo + *nt - 1;      // every consumed rectangle inside the block
+    };
+    const bool okx = place(ex0, ex1, maps[m].goal_ex, P.TX, tx0, ntx);
+    const bool oky = place(ey0, ey1, maps[m].goal_ey, P.TY, ty0, nty);
+    return okx && oky;
+}
+// will the next step() send the pending patches (the held ones among them) through the block kernel?  The conditions of step()'s fast path.
+bool Engine::lazy_region_ok() const {
+    if (!(nmaps == 1 && fuse_control && spin_wait && use_region)) return false;
+    const MapState &ms = maps[0];
+    if (!ms.have_map || !ms.goal_set || ms.initialize_search || ms.new_goal || !ms.new_start) return false;
+    if (pending.empty() || pending.size() > 4) return false;
+    int rects[4][5], n = 0;
+    for (const PatchRect &r : pending) {
+        if ((r.w + 1) * (r.h + 1) > 65 * 65) return false;
+        int *q = rects[n++]; q[0] = r.m; q[1] = r.x; q[2] = r.y; q[3] = r.w; q[4] = r.h;
+    }
+    int a, b, c, d;
+    return region_fits(rects, n, 0, &a, &b, &c, &d);
+}
+
 int Engine::patch(int m, const uint8_t *dev_patch, int x, int y, int w, int h, bool may_defer) {
     if (m < 0 || m >= nmaps || !allocated || !maps[m].have_map) return UFM_ERR_INVALID;
     if (x < 0 || y < 0 || w <= 0 || h <= 0 || x + h > L || y + w > W) return UFM_ERR_INVALID;   // Graph.cpp:38-41
     const int n = w * h;
-    {   // room for the masks of PATCH_MULTI small patches, or of one large one
-        const size_t need = std::max((size_t)PATCH_MULTI * 4096, (size_t)n);
-        if (need > d_pmask_cap) {
-            { int rc = flush_deferred(); if (rc != UFM_OK) return rc; }
-            if (d_pmask) { HIPCHK(hipStreamSynchronize(stream)); hipFree(d_pmask); d_pmask = nullptr; d_pmask_cap = 0; }
-            HIPCHK(hipMalloc(&d_pmask, need));
-            d_pmask_cap = need;
-        }
-    }
+    { int rc = flush_lazy(); if (rc != UFM_OK) return rc; }       // (held host patches come first)
+    { int rc = ensure_pmask((size_t)n); if (rc != UFM_OK) return rc; }
     // (a batch only: the patch kernel of a single map runs while the host prepares the step -- applying it inside the
     //  replan's block kernel instead was tried and saved nothing, it only made that kernel longer)
     if (may_defer && defer_patches && nmaps > 1 && n <= 4096) {
@@ -638,7 +746,9 @@ int Engine::step(ufm_stats *out) {
     ufm_stats st{};
     const auto t0 = std::chrono::steady_clock::now();
     const bool single = (nmaps == 1);
-    { int rc = flush_deferred(); if (rc != UFM_OK) return rc; }   // the patches held back: applied now, in one launch
+    // held host patches: the replan's block kernel applies them itself if this step goes that way; otherwise now, the ordinary way
+    const bool lazy_in_kernel = !lazy.empty() && lazy_region_ok();
+    if (!lazy_in_kernel) { int rc = flush_deferred(); if (rc != UFM_OK) return rc; }   // (and a batch's deferred device patches: one launch)
 
     if (!single) {
         HIPCHK(hipMemsetAsync(&P.ctr->tcount, 0, sizeof(int), stream));
@@ -764,34 +874,25 @@ int Engine::step(ufm_stats *out) {
             const bool nodes = algo != UFM_ALGO_DFM;
             // the block of one map: around its consumed rectangles; false if they do not fit into one block
             auto place_job = [&](RegionJob &j, const ReplanBegin &b, int m) {
-                if (b.nrect <= 0) return false;
-                int ex0 = INT32_MAX, ex1 = -1, ey0 = INT32_MAX, ey1 = -1;
-                for (int r = 0; r < b.nrect; ++r) {
-                    const int *qr = b.rect[r];
-                    ex0 = std::min(ex0, qr[1]); ex1 = std::max(ex1, qr[1] + qr[4] - (nodes ? 0 : 1));
-                    ey0 = std::min(ey0, qr[2]); ey1 = std::max(ey1, qr[2] + qr[3] - (nodes ? 0 : 1));
-                }
-                auto place = [&](int e0, int e1, int goal_e, int ntiles_map, int *t0, int *nt) {
-                    *nt = std::min(std::min(region_tiles, RTMAX), ntiles_map);
-                    const int tc = ((e0 + e1) / 2) / T;
-                    int lo = (goal_e >= (e0 + e1) / 2) ? tc + region_ahead - *nt + 1 : tc - region_ahead;
-                    lo = std::max(0, std::min(lo, ntiles_map - *nt));
-                    *t0 = lo;
-                    return e0 / T >= lo && e1 / T <= lo + *nt - 1;      // every consumed rectangle inside the block
-                };
-                const bool okx = place(ex0, ex1, maps[m].goal_ex, P.TX, &j.tx0, &j.ntx);
-                const bool oky = place(ey0, ey1, maps[m].goal_ey, P.TY, &j.ty0, &j.nty);
-                if (!(okx && oky)) return false;
+                if (!region_fits(b.rect, b.nrect, m, &j.tx0, &j.ntx, &j.ty0, &j.nty)) return false;
                 j.rb = b; j.rb.k_raise = iter[Q_RAISE]; j.rb.band = band;
                 j.dyn = dyn_now; j.k_lower = iter[Q_LOWER]; j.max_sweeps = region_sweeps; j.debug = region_debug;
                 j.slack = 255.0f * SQRT2F + 1.0f;     // the largest cost of one move (a diagonal through the most expensive cell)
                 j.delta = region_band > 0.0f ? region_band * 4.0f * mean_cost : INFINITY;
                 j.map = m;
+                for (int r = 0; r < 4; ++r) j.psrc[r] = nullptr;
                 return true;
             };
             if (fused && use_region) {                       // one map, a few small patches
                 regioned = place_job(rjs.j[0], rb, 0);
                 rjs.n = 1; rjs.j[0].batch = 0;
+                if (lazy_in_kernel) {                        // the held host patches are the last rectangles: the kernel applies them
+                    if (!regioned || lazy.size() > (size_t)rb.nrect) return UFM_ERR_INVALID;      // (lazy_region_ok() said otherwise: cannot happen)
+                    for (size_t i = 0; i < lazy.size(); ++i) {
+                        rjs.j[0].psrc[rb.nrect - (int)lazy.size() + (int)i] = h_lazy + (size_t)lazy[i].slot * 4096;
+                    }       // (the kernel has read them when this step returns: the slots are free again then)
+                    lazy.clear();
+                }
             } else if (!single && use_region && spin_wait && nmaps <= RJOBS && !region_rects.empty()) {
                 // a batch: one job per consuming map, every one of them with 1..4 small rectangles of its own
                 bool ok = true;
@@ -1190,6 +1291,7 @@ int engine_destroy(Engine *e) {
     if (e->d_path) hipFree(e->d_path);
     if (e->h_path) hipHostFree(e->h_path);
     if (e->h_patch) hipHostFree(e->h_patch);
+    if (e->h_lazy) hipHostFree(e->h_lazy);
     e->drop_graphs();
     if (e->h_ctr) hipHostFree(e->h_ctr);
     for (int i = 0; i < 2; ++i) if (e->h_pipe_ctr[i]) hipHostFree(e->h_pipe_ctr[i]);
@@ -1236,6 +1338,11 @@ int engine_patch(Engine *e, int m, const uint8_t *src, bool on_device, int x, in
     HIPCHK(hipSetDevice(e->device));
     if (on_device) return e->patch(m, src, x, y, w, h, true);
     if (w <= 0 || h <= 0) return UFM_ERR_INVALID;
+    {   // a small patch of a single planner: held in pinned memory for the replan's block kernel (Engine::patch_lazy)
+        bool taken = false;
+        const int rc = e->patch_lazy(m, src, x, y, w, h, &taken);
+        if (rc != UFM_OK || taken) return rc;
+    }
     const size_t n = (size_t)w * h;
     if (n > e->d_patch_cap) {
         if (e->d_patch || e->h_patch) HIPCHK(hipStreamSynchronize(e->stream));
@@ -1348,6 +1455,7 @@ int engine_read_queue(Engine *e, int m, int cap, int32_t *xy, float *g_rhs, int 
     if (!e || m < 0 || m >= e->nmaps || !e->allocated || !total || cap < 0 || (cap > 0 && (!xy || !g_rhs))) return UFM_ERR_INVALID;
     if (!e->maps[m].goal_set) return UFM_ERR_INVALID;
     HIPCHK(hipSetDevice(e->device));
+    { int rc = e->flush_deferred(); if (rc != UFM_OK) return rc; }   // (the derived RHS / the stored bytes' view read the raster)
     const size_t words = (size_t)std::max(cap, 1) * 4 + 1;          // [cap][2] int32, [cap][2] float, the count
     if (words > e->d_info_cap) {
         if (e->d_info) { HIPCHK(hipStreamSynchronize(e->stream)); hipFree(e->d_info); e->d_info = nullptr; e->d_info_cap = 0; }
@@ -1387,6 +1495,7 @@ int engine_read_info(Engine *e, int m, int x0, int y0, int nx, int ny, int32_t *
     if (e->opt_lvl == 0) return UFM_ERR_INVALID;            // level 0: the map has no Info member (void)
     if (x0 < 0 || y0 < 0 || nx <= 0 || ny <= 0 || x0 + nx > e->P.EX || y0 + ny > e->P.EY) return UFM_ERR_INVALID;
     HIPCHK(hipSetDevice(e->device));
+    { int rc = e->flush_deferred(); if (rc != UFM_OK) return rc; }   // (the derived RHS / the stored bytes' view read the raster)
     const size_t n = (size_t)nx * ny;
     if (n * 2 > e->d_info_cap) {        // device buffer kept between calls (a consumer asks window after window)
         if (e->d_info) { HIPCHK(hipStreamSynchronize(e->stream)); hipFree(e->d_info); e->d_info = nullptr; e->d_info_cap = 0; }

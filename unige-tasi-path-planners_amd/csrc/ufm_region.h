@@ -47,6 +47,9 @@ struct RegionJob {
     float delta;                          // width of the ordering band of the lowering sub-rounds (cost units; +inf: no ordering)
     int map;                              // the map of a batch this job belongs to
     int batch;                            // part of a batch step: the host has done the step bookkeeping, the last workgroup publishes
+    const uint8_t *psrc[4];               // per consumed rectangle: the patch's bytes if it has NOT been applied yet (a patch handed over from host memory:
+                                          // the bytes sit in host-coherent pinned memory and this kernel does Graph::update + the seeding itself, no patch
+                                          // kernel, no copy, no stream synchronisation in front of the replan); nullptr: applied by k_patch_small at the call
 };
 // A replan round of a batch (BASELINE config 4: every map of the GPU's share gets its own patch): one workgroup per
 // map, all in one launch.
@@ -331,6 +334,7 @@ __global__ __launch_bounds__(NTHR) void k_replan_region(DevParams P, RegionJobs 
     __shared__ uint8_t Bb[RN * RBP];
     __shared__ RegionShared S;
     __shared__ int s_last;
+    __shared__ uint8_t s_pmask[4096];     // change mask of a patch that comes with the job (<= 64 x 64 cells)
     constexpr bool CELLS = is_dfm<ALGO>;
     constexpr int COFF = CELLS ? 0 : 1;
     const int tid = threadIdx.x;
@@ -340,6 +344,36 @@ __global__ __launch_bounds__(NTHR) void k_replan_region(DevParams P, RegionJobs 
     const int rx0 = J.tx0 * T, ry0 = J.ty0 * T, rnx = J.ntx * T, rny = J.nty * T;
 
     const unsigned long long t_begin = wall_clock64();
+    // ---- 0a. the cost bytes of the block (staged first: a patch that comes with the job is applied on top of them) ----
+    {
+        const int crow = rnx + COFF, ccol = rny + COFF;
+        for (int i = tid; i < crow * ccol; i += NTHR) {
+            const int r = i / ccol, c = i - r * ccol;
+            const int cx = rx0 + r - COFF, cy = ry0 + c - COFF;
+            Cb[r * RCP + c] = (cx >= 0 && cy >= 0 && cx < P.L && cy < P.W) ? P.cost[(size_t)m * P.cstride + (size_t)cx * P.W + cy] : (uint8_t)255;
+        }
+    }
+    // ---- 0b. Graph::update (Graph.cpp:36-51) + the seeding of update() for the patches that come with the job -- what k_patch_small does for a
+    // patch applied at the call.  Every rectangle lies inside the block (place_job), so the old bytes are in Cb: compare there, write the changed
+    // ones to the raster, to the cost windows and to Cb; the change mask stays in LDS.  In the order the patches were handed over (they may overlap).
+    for (int r = 0; r < J.rb.nrect; ++r) {
+        if (!J.psrc[r]) continue;
+        const int *qr = J.rb.rect[r];                       // {map, x, y, w, h}
+        const int px = qr[1], py = qr[2], pw = qr[3], ph = qr[4];
+        __syncthreads();                                    // Cb staged / the previous rectangle's seeds read
+        for (int e = tid; e < pw * ph; e += NTHR) {
+            const int i = e / pw, j = e - i * pw;
+            uint8_t *cb = &Cb[(px + i - rx0 + COFF) * RCP + (py + j - ry0 + COFF)];
+            const uint8_t nv = J.psrc[r][e];
+            const uint8_t ch = *cb != nv;
+            s_pmask[e] = ch;
+            if (ch) { *cb = nv; P.cost[(size_t)m * P.cstride + (size_t)(px + i) * P.W + (py + j)] = nv; cost_window_store(P, m, px + i, py + j, nv); }
+        }
+        __syncthreads();
+        const int ne = CELLS ? pw * ph : (pw + 1) * (ph + 1);
+        for (int base = 0; base < ne; base += NTHR) patch_seed<!CELLS>(P, m, s_pmask, px, py, pw, ph, base + tid);
+    }
+    if (J.rb.nrect && J.psrc[J.rb.nrect - 1]) __syncthreads();      // (the seeds' list entries and counts are read below)
     // ---- 0. what k_replan_begin does: step bookkeeping, mark reset, the seeds, the invalidation bound ----
     if (tid == 0 && !J.batch) *P.dyn = J.dyn;      // (a batch: the host has put them in place before the launch -- other workgroups read them too)
     if (!J.batch) step_begin(P, J.rb.sb);
@@ -399,14 +433,6 @@ __global__ __launch_bounds__(NTHR) void k_replan_region(DevParams P, RegionJobs 
         const int x = rx0 + hx, y = ry0 + hy;
         const bool in = x >= 0 && y >= 0 && x < P.TX * T && y < P.TY * T;
         Gs[(hx + 1) * RP + hy + 1] = in ? P.G[gaddr(P, m, x, y)] : INFINITY;
-    }
-    {
-        const int crow = rnx + COFF, ccol = rny + COFF;
-        for (int i = tid; i < crow * ccol; i += NTHR) {
-            const int r = i / ccol, c = i - r * ccol;
-            const int cx = rx0 + r - COFF, cy = ry0 + c - COFF;
-            Cb[r * RCP + c] = (cx >= 0 && cy >= 0 && cx < P.L && cy < P.W) ? P.cost[(size_t)m * P.cstride + (size_t)cx * P.W + cy] : (uint8_t)255;
-        }
     }
     // the seeds: every patch that holds an element of a consumed rectangle (a superset of the changed cells' elements;
     // a sweep that finds nothing to do costs a fraction of a microsecond)

@@ -45,6 +45,8 @@ __global__ __launch_bounds__(OWNK == 2 ? NTHR / 2 : NTHR, UFM_RELAX_WAVES) void 
     __shared__ int s_se[OWN ? 256 : 1];       // resident kernel: start elements of the first 64 maps (index into G, -1 unused) ...
     __shared__ float s_sh[OWN ? 256 : 1];     // ... and hm * dist(start, element)
     __shared__ int s_late;      // resident kernel: thread 0 has seen the time limit pass (no more tiles are taken ahead: the next look leaves)
+    __shared__ int s_held;      // resident kernel, P.dag_on: the last decision saw a queued tile of this workgroup that is still waiting for first visits of its neighbours
+    __shared__ int s_pd[OWN ? NTH : 1];      // ... and the counts of those (dag_left) for this workgroup's first queue words, loaded with s_pf
     __shared__ int s_own[4];    // resident kernel, thread 0's book-keeping: 0 slot whose mark is still to be taken back, 1 slot being visited, 2 visits
     __shared__ unsigned long long s_stat[3];   // thread 4's per-workgroup statistics (visits, sweeps, evaluations), flushed once at the end
     // resident kernel, node planners: border values are handed to the neighbours DURING the visit (early hand-off, below):
@@ -131,6 +133,7 @@ __global__ __launch_bounds__(OWNK == 2 ? NTHR / 2 : NTHR, UFM_RELAX_WAVES) void 
     int own_next = -1, own_slot_now = -1;   // (the same in every thread)
     int own_hrot = 0;                       // which part of the hints the visit in progress has loaded ahead
     [[maybe_unused]] int look_rot = 0;      // ... and which part the look of an idle workgroup loads
+    [[maybe_unused]] int held_looks = 0;    // P.dag_on: looks in a row that found only held tiles
     const unsigned long long own_t0 = OWN ? wall_clock64() : 0ull;
     if (OWN && tid == 0) { s_own[0] = -1; s_own[1] = -1; s_own[2] = 0; s_late = 0; }
     if constexpr (OWN) {   // the start elements of the first 64 maps: address in G and the heuristic term of their keys (start_bound())
@@ -163,11 +166,13 @@ __global__ __launch_bounds__(OWNK == 2 ? NTHR / 2 : NTHR, UFM_RELAX_WAVES) void 
                 if (tid < P.own_nw && tid != (int)blockIdx.x) hint = __hip_atomic_load(&P.own_min[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #endif
                 const int v0 = tid < P.own_slots ? __hip_atomic_load(&own_q[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : INFBITS;
+                const int d0 = (P.dag_on && tid < P.own_slots) ? __hip_atomic_load(&P.dag_left[own_base + tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
                 const int aborted = tid == 0 ? __hip_atomic_load(&P.ctr->own_abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
-                own_decide(v0, hint, -1);
+                own_decide(v0, hint, -1, d0, held_looks >= P.dag_patience);
                 const unsigned long long b = s_best;
                 const int votes = s_gmin;
                 const bool have = b != ~0ull;
+                held_looks = (!have && s_held) ? held_looks + 1 : 0;      // (the same in every thread: s_best / s_held are read behind own_decide's closing barrier)
                 const bool take = have && !(votes & 2);        // inside the ordering band
                 bool stop = false;
                 if (!have && !(votes & 1) && blockIdx.x == 0) {
@@ -329,6 +334,21 @@ __global__ __launch_bounds__(OWNK == 2 ? NTHR / 2 : NTHR, UFM_RELAX_WAVES) void 
         // resident kernel: the values of the map's start elements, one per lane (for the end condition below)
         const int own_sa = (OWN && focused && tid < 4 && m < 64) ? s_se[m * 4 + tid] : -1;
         const float own_sg = own_sa >= 0 ? ld_f<OWN>(&P.G[own_sa]) : INFINITY;
+        // P.dag_on: the arrival estimate of this tile and the thresholds of its eight neighbours (lane 0..8, 4 = this tile): after its FIRST visit the
+        // tile counts itself off at every neighbour that was waiting for it (the activations' lanes, below)
+        float dag_mine = 0.0f, dag_nthr = -INFINITY;
+        int dag_nslot = -1;
+        if constexpr (OWN) if (P.dag_on && tid < 9 && tid != 4) {
+            const int ntx = tx + tid / 3 - 1, nty = ty + tid % 3 - 1;
+            if (ntx >= 0 && ntx < P.TX && nty >= 0 && nty < P.TY) {
+                const int ngt = m * P.NTm + ntx * P.TY + nty;
+                int o_, s_;
+                own_locate(P, ngt, o_, s_);
+                dag_nslot = o_ * P.own_slots + s_;
+                dag_nthr = P.dag_thr[ngt];
+                dag_mine = P.dag_a[gt];
+            }
+        }
         if (tid == 0) {
             const int seen = atomicAdd(&P.touched[gt], 1);   // visits of this tile in the current step
             const int first = seen == 0;
@@ -499,6 +519,7 @@ __global__ __launch_bounds__(OWNK == 2 ? NTHR / 2 : NTHR, UFM_RELAX_WAVES) void 
             typedef __attribute__((address_space(3))) void *lds_ptr;
             typedef const __attribute__((address_space(1))) void *glb_ptr;
             __builtin_amdgcn_global_load_lds((glb_ptr)(own_q + min(tid, P.own_slots - 1)), (lds_ptr)(s_pf + (tid & ~63)), 4, 0, 16);              // (16: sc1)
+            if (P.dag_on) __builtin_amdgcn_global_load_lds((glb_ptr)(P.dag_left + own_base + min(tid, P.own_slots - 1)), (lds_ptr)(s_pd + (tid & ~63)), 4, 0, 16);
             // (the hints: a different quarter or half of them at every visit -- the band is a heuristic, 2 KB of hints per visit next to
             //  1.8 KB of tile data is not)
             ++own_hrot;
@@ -721,7 +742,7 @@ __global__ __launch_bounds__(OWNK == 2 ? NTHR / 2 : NTHR, UFM_RELAX_WAVES) void 
             // exchange is on its way while this visit is written back, and the next visit's loads follow the write-back with no
             // queue round trip in between.  (A fresh look costs two round trips in a row -- words, then exchange -- per visit.)
             own_decide(tid < P.own_slots ? s_pf[tid] : INFBITS, (tid < UFM_HINT_SAMPLE && (tid + own_hrot * UFM_HINT_SAMPLE) % P.own_nw != (int)blockIdx.x) ? s_pfh[tid] : INFBITS,
-                       (own_slot_now >= own_base && own_slot_now < own_base + P.own_slots) ? own_slot_now - own_base : -1);
+                       (own_slot_now >= own_base && own_slot_now < own_base + P.own_slots) ? own_slot_now - own_base : -1, (P.dag_on && tid < P.own_slots) ? s_pd[tid] : 0, false);
             const unsigned long long b = s_best;
             const bool take = b != ~0ull && !(s_gmin & 2) && !(P.own_flags & 1) && !s_late;
             if (tid == 0) {
@@ -781,6 +802,8 @@ __global__ __launch_bounds__(OWNK == 2 ? NTHR / 2 : NTHR, UFM_RELAX_WAVES) void 
                     else activate(P, Q, k + 1, m * P.NTm + ntx * P.TY + nty, s_bmin[tid]);
                 }
             }
+            if constexpr (OWN) if (tid != 4 && dag_nslot >= 0 && s_misc[0] && dag_mine < dag_nthr)      // first visit done: whoever waited for it has one less to wait for
+                __hip_atomic_fetch_sub(&P.dag_left[dag_nslot], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
 #ifdef UFM_TIMING
         if (MODE == MODE_LOWER) {
