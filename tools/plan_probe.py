@@ -31,7 +31,7 @@ for rep in range(3):
     s = p.stats
     g = p.g()
     fin = np.isfinite(g)
-    print("%s %d^2 seed %d %s tile %d: plan %.2f ms, resident kernel %.2f ms (stops %d), visits %d (resident %d), launches %d, expanded %d, finite %d, crc %08x, layout %s, back-pointers %s" % (
-        algo, size, seed, kv, p.L.ufm_tile_edge(), dt * 1e3, s.resident_kernel_ms, s.resident_stops, s.tile_visits, s.resident_tile_visits, s.launches,
+    print("%s %d^2 seed %d %s tile %d: plan %.2f ms, resident kernel %.2f ms (stops %d), visits %d (resident %d), evals/elem %.1f, launches %d, expanded %d, finite %d, crc %08x, layout %s, back-pointers %s" % (
+        algo, size, seed, kv, p.L.ufm_tile_edge(), dt * 1e3, s.resident_kernel_ms, s.resident_stops, s.tile_visits, s.resident_tile_visits, s.elem_evals / max(1, g.size), s.launches,
         s.expanded, int(fin.sum()), zlib.crc32(np.ascontiguousarray(g).tobytes()), p.check_layout(), p.check_info() if algo != "DFM" else "-"), flush=True)
 p.close()

@@ -78,6 +78,14 @@ constexpr int NTHR = 1024;     // 16 waves; four lanes per node, each wave owns 
 #ifndef UFM_IDLE_SLEEP
 #define UFM_IDLE_SLEEP 4
 #endif
+#ifndef UFM_DIRWAKE
+#define UFM_DIRWAKE 0          // resident kernel: a re-visit wakes the patches along the halo entries that changed since the tile's last visit, not all sixteen
+#endif                         // (round 4, measured, diagnostic builds only: FD 4096^2 evaluations per element 29.3 -> 27.4, plan kernel 14.10 -> 14.50 ms; 8192^2 24.3 -> 22.9,
+                               //  35.1 -> 35.7 ms; MS-DFM 2048^2 100 -> 97, 11.35 -> 11.6 ms: the kernel is bound by its chain of dependent visits, not by its work -- DESIGN.md 11)
+#ifndef UFM_DAG
+#define UFM_DAG 0              // round 4 experiment, diagnostic builds only (tools/dag_probe.py, lib build/exp/libufm_dag.so): first visits of the resident
+#endif                         // kernel gated by an arrival estimate (DevParams::dag_*).  Measured: -28 % tile visits, -36 % evaluations, +10 % time.
+constexpr bool DAG = UFM_DAG != 0;
 // HBM layout of the field: tile-major.  A tile's T x T values are contiguous
 // (1 KB for T = 16: eight 128-B lines); next to them every tile keeps a *ring*: copies of the border
 // values of its eight neighbours (top row, bottom row, left column, right column, four corners --
@@ -157,6 +165,8 @@ struct DevParams {
     uint8_t *bp;                // [NT][T][T] back-pointers (the level-1/2 planners' INFO, FD impl:86-111, SG :131-166, DFM :73-99), same layout as G: which of
                                 // the operator's candidates gives the element's value, and which of its inputs that leans on (bp_byte); BP_NONE: goal / never set
     float *ring;                // [NT][RING] border values of each tile's eight neighbours (+inf where there is none)
+    float *seen;                // [NT][RING] resident kernel: the halo values a tile's last visit converged against (entries as `ring`), [RING - 1] = 1.0f if that
+                                // visit did converge: a later visit of the same step wakes only the patches along halo entries that have changed since (UFM_DIRWAKE)
     uint8_t *cost;              // [nmaps][L][W] the raster (Graph::map_)
     uint8_t *costT;             // [NT][CTS] per tile, the cost bytes its visit needs: cells (x0-1..x0+T-1, y0-1..y0+T-1) of a
                                 // node tile, (x0..x0+T-1, y0..y0+T-1) of a cell tile (DFM), row-major; 255 outside the map

@@ -183,7 +183,7 @@ void Engine::release() {
     drop_graphs();                       // captured kernel arguments hold these pointers
     deferred.clear();
     std::memset(&graph_sig, 0, sizeof(graph_sig));
-    void *ptrs[] = {P.G, P.Gprev, P.bp, P.ring, P.cost, P.costT, P.goal, P.cand, P.ready, P.hint, P.rank, P.park, P.pflag, P.pprio,
+    void *ptrs[] = {P.G, P.Gprev, P.bp, P.ring, P.seen, P.cost, P.costT, P.goal, P.cand, P.ready, P.hint, P.rank, P.park, P.pflag, P.pprio,
                     P.queued, P.prio, P.start, P.bnd, P.dyn, P.spos, P.touched, P.fresh, P.tlist, P.sflag, P.slist, P.slist2,
                     P.mark, P.num_updated, P.consume, P.lmax, P.own_prio, P.own_lock, P.own_min, P.dag_a, P.dag_thr, P.dag_left, P.ctr, d_scratch};
     for (void *q : ptrs) if (q) hipFree(q);
@@ -225,6 +225,7 @@ int Engine::alloc(int width, int length) {
     dmalloc(P.Gprev, gbytes);
     dmalloc(P.bp, P.gstride * nmaps);
     dmalloc(P.ring, (size_t)P.NT * RING * sizeof(float));
+    dmalloc(P.seen, UFM_DIRWAKE ? (size_t)P.NT * RING * sizeof(float) : sizeof(float));
     dmalloc(P.cost, P.cstride * nmaps);
     dmalloc(P.costT, (size_t)P.NT * CTS);
     dmalloc(P.goal, sizeof(int) * 2 * nmaps);
@@ -482,7 +483,7 @@ int Engine::owned_phase() {
     //  SG 2048^2 7.08 against 6.55, 1024^2 3.40 against 2.84; MS-DFM, whose visits are longer and which has no early hand-off, 2048^2 13.1 against 15.0)
     const bool half = T == 16 && (owned_waves == 8 || (owned_waves == 0 && (nmaps > 1 || P.NTm > (algo == UFM_ALGO_DFM ? 12000 : 50000))));
     own_layout(half ? 5 : 4);
-    P.dag_on = (dag_mode != 0 && dag_have) ? 1 : 0;
+    P.dag_on = (DAG && dag_mode != 0 && dag_have) ? 1 : 0;
     P.dag_patience = dag_patience;
     if (P.dag_on) k_dag_setup<<<256, 256, 0, stream>>>(P, dag_kappa);
     k_own_import<<<64, 256, 0, stream>>>(P, k);

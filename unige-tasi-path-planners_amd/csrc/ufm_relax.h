@@ -44,9 +44,10 @@ __global__ __launch_bounds__(OWNK == 2 ? NTHR / 2 : NTHR, UFM_RELAX_WAVES) void 
     __shared__ int s_pfh[OWN ? OWN_NW : 1];   // start of the visit in progress (loaded straight into LDS while it sweeps)
     __shared__ int s_se[OWN ? 256 : 1];       // resident kernel: start elements of the first 64 maps (index into G, -1 unused) ...
     __shared__ float s_sh[OWN ? 256 : 1];     // ... and hm * dist(start, element)
+    __shared__ int s_wsel[2];   // resident kernel, UFM_DIRWAKE: [0] the visit ends at the end condition (no sweeps), [1] the tile's last visit converged (its `seen` record is complete)
     __shared__ int s_late;      // resident kernel: thread 0 has seen the time limit pass (no more tiles are taken ahead: the next look leaves)
     __shared__ int s_held;      // resident kernel, P.dag_on: the last decision saw a queued tile of this workgroup that is still waiting for first visits of its neighbours
-    __shared__ int s_pd[OWN ? NTH : 1];      // ... and the counts of those (dag_left) for this workgroup's first queue words, loaded with s_pf
+    __shared__ int s_pd[(OWN && DAG) ? NTH : 1];      // ... and the counts of those (dag_left) for this workgroup's first queue words, loaded with s_pf
     __shared__ int s_own[4];    // resident kernel, thread 0's book-keeping: 0 slot whose mark is still to be taken back, 1 slot being visited, 2 visits
     __shared__ unsigned long long s_stat[3];   // thread 4's per-workgroup statistics (visits, sweeps, evaluations), flushed once at the end
     // resident kernel, node planners: border values are handed to the neighbours DURING the visit (early hand-off, below):
@@ -166,13 +167,13 @@ __global__ __launch_bounds__(OWNK == 2 ? NTHR / 2 : NTHR, UFM_RELAX_WAVES) void 
                 if (tid < P.own_nw && tid != (int)blockIdx.x) hint = __hip_atomic_load(&P.own_min[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #endif
                 const int v0 = tid < P.own_slots ? __hip_atomic_load(&own_q[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : INFBITS;
-                const int d0 = (P.dag_on && tid < P.own_slots) ? __hip_atomic_load(&P.dag_left[own_base + tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
+                const int d0 = (DAG && P.dag_on && tid < P.own_slots) ? __hip_atomic_load(&P.dag_left[own_base + tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
                 const int aborted = tid == 0 ? __hip_atomic_load(&P.ctr->own_abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
-                own_decide(v0, hint, -1, d0, held_looks >= P.dag_patience);
+                own_decide(v0, hint, -1, d0, DAG && held_looks >= P.dag_patience);
                 const unsigned long long b = s_best;
                 const int votes = s_gmin;
                 const bool have = b != ~0ull;
-                held_looks = (!have && s_held) ? held_looks + 1 : 0;      // (the same in every thread: s_best / s_held are read behind own_decide's closing barrier)
+                if constexpr (DAG) held_looks = (!have && s_held) ? held_looks + 1 : 0;      // (the same in every thread: s_best / s_held are read behind own_decide's closing barrier)
                 const bool take = have && !(votes & 2);        // inside the ordering band
                 bool stop = false;
                 if (!have && !(votes & 1) && blockIdx.x == 0) {
@@ -327,6 +328,10 @@ __global__ __launch_bounds__(OWNK == 2 ? NTHR / 2 : NTHR, UFM_RELAX_WAVES) void 
         constexpr int CN = CROWS * CROWS;
         const float gl0 = ld_f<OWN>(&Gt[io_on ? tid : 0]);
         const float hv = ld_f<OWN>(&ring[ht >= 0 ? ht : 0]);
+        constexpr bool DIRWAKE = OWN && UFM_DIRWAKE && MODE == MODE_LOWER;
+        float *seen = DIRWAKE ? P.seen + (size_t)gt * RING : nullptr;
+        // (thread ht == -1 loads the record's "complete" flag)
+        const float sv = (DIRWAKE && ht >= -1) ? ld_f<OWN>(&seen[ht >= 0 ? ht : RING - 1]) : 0.0f;
         const int c0 = ct[tid < CN ? tid : 0];
         constexpr bool BPRAISE = MODE == MODE_RAISE && !is_dfm<ALGO>;   // invalidation along the stored back-pointers
         const int bp0 = BPRAISE ? P.bp[(size_t)gt * TT + (io_on ? tid : 0)] : BP_NONE;
@@ -336,9 +341,9 @@ __global__ __launch_bounds__(OWNK == 2 ? NTHR / 2 : NTHR, UFM_RELAX_WAVES) void 
         const float own_sg = own_sa >= 0 ? ld_f<OWN>(&P.G[own_sa]) : INFINITY;
         // P.dag_on: the arrival estimate of this tile and the thresholds of its eight neighbours (lane 0..8, 4 = this tile): after its FIRST visit the
         // tile counts itself off at every neighbour that was waiting for it (the activations' lanes, below)
-        float dag_mine = 0.0f, dag_nthr = -INFINITY;
-        int dag_nslot = -1;
-        if constexpr (OWN) if (P.dag_on && tid < 9 && tid != 4) {
+        [[maybe_unused]] float dag_mine = 0.0f, dag_nthr = -INFINITY;
+        [[maybe_unused]] int dag_nslot = -1;
+        if constexpr (OWN && DAG) if (P.dag_on && tid < 9 && tid != 4) {
             const int ntx = tx + tid / 3 - 1, nty = ty + tid % 3 - 1;
             if (ntx >= 0 && ntx < P.TX && nty >= 0 && nty < P.TY) {
                 const int ngt = m * P.NTm + ntx * P.TY + nty;
@@ -355,7 +360,8 @@ __global__ __launch_bounds__(OWNK == 2 ? NTHR / 2 : NTHR, UFM_RELAX_WAVES) void 
             if (first) P.tlist[atomicAdd(&P.ctr->tcount, 1)] = gt;
             s_misc[0] = first; s_misc[1] = seen; s_misc[2] = 0; s_misc[3] = 0; s_idle = 0; s_giveup = 0;
         }
-        if (tid < NWV) s_wake[tid] = (1 << PPWK) - 1;
+        if (tid < NWV) s_wake[tid] = DIRWAKE ? 0 : (1 << PPWK) - 1;      // (DIRWAKE: set behind the staging barrier, when it is known what there is to wake)
+        if (DIRWAKE && ht == -1) s_wsel[1] = (sv == 1.0f) ? 1 : 0;
         bool own_parked = false;      // (thread 0)
         if constexpr (OWN) if (focused && w == 0) {
             // End condition: a tile whose priority lies beyond its map's start key (start_bound(): the largest key among the
@@ -375,6 +381,7 @@ __global__ __launch_bounds__(OWNK == 2 ? NTHR / 2 : NTHR, UFM_RELAX_WAVES) void 
                 }
             }
         }
+        if (DIRWAKE && tid == 0) s_wsel[0] = own_parked ? 1 : 0;
         if (tid >= 32 && tid < 41) s_bmin[tid - 32] = INFBITS;
 
         // the tile (contiguous) and its halo: the ring record, in this order (RING_*)
@@ -398,6 +405,36 @@ __global__ __launch_bounds__(OWNK == 2 ? NTHR / 2 : NTHR, UFM_RELAX_WAVES) void 
         }
         if constexpr (EARLY) { if (io_on) Os[tid] = gl0; if (tid < NWV * 9) s_emin[tid] = INFBITS; if (tid == 0) { s_qw[0] = OWN_MARK; s_qw[1] = own_parked ? 0x20000 : 0; } }
         __syncthreads();
+        // the halo entry of thread ht (>= 0) inside the staged tile: row / column -1 or T
+        auto halo_rc = [&](int &hr, int &hc) {
+            if (ht < T) { hr = -1; hc = ht; }
+            else if (ht < 2 * T) { hr = T; hc = ht - T; }
+            else if (ht < 3 * T) { hr = ht - 2 * T; hc = -1; }
+            else if (ht < 4 * T) { hr = ht - 3 * T; hc = T; }
+            else { hr = (ht & 2) ? T : -1; hc = (ht & 1) ? T : -1; }
+        };
+        if constexpr (DIRWAKE) {
+            // What is there to sweep?  The tile's first visit of the step, or one after a visit that ran into the sweep cap: everything.  Otherwise the
+            // tile's own values are a fixed point of the halo its last visit saw (`seen`): only the patches along halo entries that have changed since
+            // can have anything to do -- the others are woken by their neighbours if it comes to that.  (Round 3 woke all sixteen at every visit: half of
+            // the 7.6 M patch sweeps of a 4096^2 plan that found nothing to do.)  A visit that finds no changed entry at all ends after the vote.
+            if (!s_wsel[0]) {
+                if (s_misc[0] || !s_wsel[1]) { if (tid < NWV) s_wake[tid] = (1 << PPWK) - 1; }
+                else if (ht >= 0 && __float_as_int(hv) != __float_as_int(sv)) {
+                    int hr, hc;
+                    halo_rc(hr, hc);
+                    const int r0 = max(hr - 1, 0) / 4, r1 = min(hr + 1, T - 1) / 4, c0_ = max(hc - 1, 0) / 4, c1 = min(hc + 1, T - 1) / 4;
+                    for (int pr_ = r0; pr_ <= r1; ++pr_)
+                        for (int pc_ = c0_; pc_ <= c1; ++pc_) {
+                            int wv, bit;
+                            if constexpr (SKEW) { wv = (pr_ + 2 * pc_) & 7; bit = (pc_ == (wv < 4 ? 0 : (wv >> 1) - 1)) ? 1 : 2; }
+                            else { wv = (pr_ / PR) * 4 + (pc_ / PR); bit = 1 << ((pr_ % PR) * PR + (pc_ % PR)); }
+                            __hip_atomic_fetch_or(&s_wake[wv], bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        }
+                }
+            }
+            lds_barrier();
+        }
         UFM_TICK(tk1);
 #ifdef UFM_TIMING
         const int dbg_hint = P.hint[gt];
@@ -519,7 +556,7 @@ __global__ __launch_bounds__(OWNK == 2 ? NTHR / 2 : NTHR, UFM_RELAX_WAVES) void 
             typedef __attribute__((address_space(3))) void *lds_ptr;
             typedef const __attribute__((address_space(1))) void *glb_ptr;
             __builtin_amdgcn_global_load_lds((glb_ptr)(own_q + min(tid, P.own_slots - 1)), (lds_ptr)(s_pf + (tid & ~63)), 4, 0, 16);              // (16: sc1)
-            if (P.dag_on) __builtin_amdgcn_global_load_lds((glb_ptr)(P.dag_left + own_base + min(tid, P.own_slots - 1)), (lds_ptr)(s_pd + (tid & ~63)), 4, 0, 16);
+            if (DAG && P.dag_on) __builtin_amdgcn_global_load_lds((glb_ptr)(P.dag_left + own_base + min(tid, P.own_slots - 1)), (lds_ptr)(s_pd + (tid & ~63)), 4, 0, 16);
             // (the hints: a different quarter or half of them at every visit -- the band is a heuristic, 2 KB of hints per visit next to
             //  1.8 KB of tile data is not)
             ++own_hrot;
@@ -742,7 +779,7 @@ __global__ __launch_bounds__(OWNK == 2 ? NTHR / 2 : NTHR, UFM_RELAX_WAVES) void 
             // exchange is on its way while this visit is written back, and the next visit's loads follow the write-back with no
             // queue round trip in between.  (A fresh look costs two round trips in a row -- words, then exchange -- per visit.)
             own_decide(tid < P.own_slots ? s_pf[tid] : INFBITS, (tid < UFM_HINT_SAMPLE && (tid + own_hrot * UFM_HINT_SAMPLE) % P.own_nw != (int)blockIdx.x) ? s_pfh[tid] : INFBITS,
-                       (own_slot_now >= own_base && own_slot_now < own_base + P.own_slots) ? own_slot_now - own_base : -1, (P.dag_on && tid < P.own_slots) ? s_pd[tid] : 0, false);
+                       (own_slot_now >= own_base && own_slot_now < own_base + P.own_slots) ? own_slot_now - own_base : -1, (DAG && P.dag_on && tid < P.own_slots) ? s_pd[tid] : 0, false);
             const unsigned long long b = s_best;
             const bool take = b != ~0ull && !(s_gmin & 2) && !(P.own_flags & 1) && !s_late;
             if (tid == 0) {
@@ -756,6 +793,17 @@ __global__ __launch_bounds__(OWNK == 2 ? NTHR / 2 : NTHR, UFM_RELAX_WAVES) void 
         //  the tests below ahead of the tile loop and carries them through the sweeps -- registers the sweep loop needs)
         int wb_r = io_r, wb_c = io_c;
         asm volatile("" : "+v"(wb_r), "+v"(wb_c));
+        if constexpr (DIRWAKE) if (!s_wsel[0]) {      // the halo this visit has converged against (as staged, plus what an in-visit refresh took in), and whether it did converge
+            if (ht >= 0) {
+                int hr, hc;
+                halo_rc(hr, hc);
+                const float hcur = Gs[(hr + 1) * GP + hc + 1];
+                if (__float_as_int(hcur) != __float_as_int(sv)) st_f<OWN>(&seen[ht], hcur);
+            } else if (ht == -1) {
+                const float f = conv ? 1.0f : 0.0f;
+                if (f != sv) st_f<OWN>(&seen[RING - 1], f);
+            }
+        }
         const float gref = EARLY ? (io_on ? Os[tid] : 0.0f) : gl0;   // what HBM holds (early hand-off: as last written during the visit)
         const float gf = io_on ? Gs[(wb_r + 1) * GP + wb_c + 1] : gref;
         if (gf != gref) {
@@ -802,7 +850,7 @@ __global__ __launch_bounds__(OWNK == 2 ? NTHR / 2 : NTHR, UFM_RELAX_WAVES) void 
                     else activate(P, Q, k + 1, m * P.NTm + ntx * P.TY + nty, s_bmin[tid]);
                 }
             }
-            if constexpr (OWN) if (tid != 4 && dag_nslot >= 0 && s_misc[0] && dag_mine < dag_nthr)      // first visit done: whoever waited for it has one less to wait for
+            if constexpr (OWN && DAG) if (tid != 4 && dag_nslot >= 0 && s_misc[0] && dag_mine < dag_nthr)      // first visit done: whoever waited for it has one less to wait for
                 __hip_atomic_fetch_sub(&P.dag_left[dag_nslot], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
 #ifdef UFM_TIMING
