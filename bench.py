@@ -80,12 +80,17 @@ def cpu_worker(spec):
     assert p.step() == 0
     exp += p.num_expanded; ms += p.u_time + p.p_time
     plan_exp, plan_ms = exp, ms
+    # (the replans also count the elements whose G differs after the step -- the engine's definition of a cell updated, next to the reference's
+    #  own count of queue pops: both are in the line.  The bookkeeping is one compare per G assignment, inside the replans' clock.)
+    p.track_changes(True)
+    changed = 0
     for k, s, top, left, patch in ufm_amd.synth.replan_script(seed, size, size, n_patches=spec["patches"]):
         p.patch_map(patch, top, left); p.set_start(*s)
         assert p.step() == 0
         exp += p.num_expanded; ms += p.u_time + p.p_time
+        changed += p.num_changed
     print(json.dumps({"expanded": exp, "ms": ms, "wall_s": time.perf_counter() - t0, "plan_ms": plan_ms, "plan_expanded": plan_exp,
-                      "replans_ms": ms - plan_ms, "replans_expanded": exp - plan_exp}))
+                      "replans_ms": ms - plan_ms, "replans_expanded": exp - plan_exp, "replans_changed": changed}))
 
 
 def cpu_baseline(size, seed, n_patches, algo_name, heuristic, n_maps):
@@ -111,7 +116,9 @@ def cpu_baseline(size, seed, n_patches, algo_name, heuristic, n_maps):
     # the same split as the GPU line's "phases": the reference's own clocks (u_time + p_time) of the first step and of the replans,
     # the slowest process of a batch
     phases = {"plan_ms": max(r["plan_ms"] for r in results), "replans_ms": max(r["replans_ms"] for r in results),
-              "plan_cells": sum(r["plan_expanded"] for r in results), "replans_cells": sum(r["replans_expanded"] for r in results)}
+              "plan_cells": sum(r["plan_expanded"] for r in results), "replans_cells": sum(r["replans_expanded"] for r in results),
+              "replans_cells_changed": sum(r["replans_changed"] for r in results),
+              "note": "cells = the reference's num_nodes_expanded (queue pops); replans_cells_changed = elements whose G differs after the step, the definition of the GPU line's phases.replans_cells"}
     return {"value": value, "unit": "cells/s", "cores": used, "cores_used": used, "cores_host": cores_host, "kind": "port", "phases": phases,
             "sample": "%s-%d%s %dx%d, %s, full plan + %d replans each: %s" % (
                 algo_name, opt_level(algo_name), " heuristic keys" if heuristic else "", size, size,

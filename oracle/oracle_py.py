@@ -60,7 +60,8 @@ def lib():
         for n in ("orc_g", "orc_rhs", "orc_inmap", "orc_bptr"):
             getattr(L, n).restype = C.c_void_p
             getattr(L, n).argtypes = [vp]
-        for n in ("orc_num_expanded", "orc_num_updated", "orc_map_size", "orc_queue_size"):
+        L.orc_track_changes.argtypes = [vp, i]
+        for n in ("orc_num_expanded", "orc_num_updated", "orc_map_size", "orc_queue_size", "orc_num_changed"):
             getattr(L, n).restype = C.c_ulong
             getattr(L, n).argtypes = [vp]
         for n in ("orc_u_time_ms", "orc_p_time_ms"):
@@ -204,6 +205,14 @@ class OraclePlanner:
     @property
     def num_expanded(self):
         return self.L.orc_num_expanded(self.h)
+
+    def track_changes(self, on=True):
+        self.L.orc_track_changes(self.h, int(on))
+
+    @property
+    def num_changed(self):
+        """elements whose G differs after the last step from before it (needs track_changes(); the engine's num_nodes_expanded)"""
+        return self.L.orc_num_changed(self.h)
 
     @property
     def num_updated(self):

@@ -65,6 +65,12 @@ struct orc_planner {
     int start_set;
     int runaway;   /* the last plan() hit expansion_cap() */
     int revision;  /* ORC_REV_CURRENT (the sources as they stand) or bits of ORC_REV_LOG (see orc_set_revision) */
+    /* orc_track_changes(): which elements' G a step touched, with the value each had before -- to count the elements whose G
+     * DIFFERS after a step, the engine's definition of "cells updated" (num_nodes_expanded counts queue pops) */
+    int chg_on;
+    uint32_t chg_step, *chg_stamp;
+    float *chg_g0;
+    int *chg_list, chg_n;
 };
 
 /* ---------------- keys: std::pair lexicographic / float --------------- */
@@ -153,6 +159,11 @@ static inline int eidx(const orc_t *p, int x, int y) { return x * p->ny + y; }
 /* ExpandedMap_impl.h:5-14 find_or_init */
 static inline void find_or_init(orc_t *p, int e) {
     if (!p->inmap[e]) { p->inmap[e] = 1; p->map_size++; }
+}
+/* G(s) = v of plan() (FD impl:44,58,84,105 ...), with the bookkeeping of orc_track_changes() */
+static inline void set_g(orc_t *p, int s, float v) {
+    if (p->chg_on && p->chg_n >= 0 && p->chg_stamp[s] != p->chg_step) { p->chg_stamp[s] = p->chg_step; p->chg_g0[s] = p->g[s]; p->chg_list[p->chg_n++] = s; }
+    p->g[s] = v;
 }
 /* ExpandedMap_impl.h:16-28 insert_or_assign */
 static inline void insert_or_assign(orc_t *p, int e, float g, float rhs) {
@@ -509,7 +520,7 @@ static void plan0(orc_t *p) {
         if (++expanded > expansion_cap(p)) { p->runaway = 1; break; }
         int sx = s / p->ny, sy = s % p->ny;
         int under = !(p->g[s] > p->rhs[s]);
-        p->g[s] = under ? INFINITY : p->rhs[s];
+        set_g(p, s, under ? INFINITY : p->rhs[s]);
         for (int i = 0; i < 8; ++i) {
             int qx = sx + N8_DX[i], qy = sy + N8_DY[i];
             if (!valid_elem(p, qx, qy)) continue;
@@ -537,7 +548,7 @@ static void plan12_node(orc_t *p) {
         ++expanded;
         int sx = s / p->ny, sy = s % p->ny;
         if (p->g[s] > p->rhs[s]) {
-            p->g[s] = p->rhs[s];
+            set_g(p, s, p->rhs[s]);
             pq_pop(p);
             if (p->lvl == 2) { /* SG<2>: diagonal then orthogonal neighbours */
                 for (int i = 0; i < 4; ++i) {
@@ -570,7 +581,7 @@ static void plan12_node(orc_t *p) {
                 }
             }
         } else {
-            p->g[s] = INFINITY;
+            set_g(p, s, INFINITY);
             for (int i = 0; i < 8; ++i) {
                 int qx = sx + N8_DX[i], qy = sy + N8_DY[i];
                 if (!valid_elem(p, qx, qy)) continue;
@@ -604,7 +615,7 @@ static void plan1_dfm(orc_t *p) {
         ++expanded;
         int sx = s / p->ny, sy = s % p->ny;
         if (p->g[s] > p->rhs[s]) {
-            p->g[s] = p->rhs[s];
+            set_g(p, s, p->rhs[s]);
             pq_pop(p);
             for (int i = 0; i < 8; ++i) {
                 int qx = sx + N8_DX[i], qy = sy + N8_DY[i];
@@ -618,7 +629,7 @@ static void plan1_dfm(orc_t *p) {
                 enqueue_if_inconsistent(p, q);
             }
         } else {
-            p->g[s] = INFINITY;
+            set_g(p, s, INFINITY);
             for (int i = 0; i < 8; ++i) {
                 int qx = sx + N8_DX[i], qy = sy + N8_DY[i];
                 if (!valid_elem(p, qx, qy)) continue;
@@ -705,6 +716,7 @@ orc_t *orc_create(int algo, int opt_lvl, int use_heuristic) {
 static void free_state(orc_t *p) {
     free(p->g); free(p->rhs); free(p->inmap); free(p->bptr);
     free(p->heap); free(p->hkey); free(p->hpos);
+    free(p->chg_stamp); free(p->chg_g0); free(p->chg_list); p->chg_stamp = NULL; p->chg_g0 = NULL; p->chg_list = NULL; p->chg_on = 0;
     p->g = p->rhs = NULL; p->inmap = NULL; p->bptr = NULL; p->heap = NULL; p->hkey = NULL; p->hpos = NULL;
 }
 void orc_destroy(orc_t *p) {
@@ -800,10 +812,28 @@ static double now_ms(void) {
     clock_gettime(CLOCK_MONOTONIC, &ts);
     return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6;
 }
+/* Test / benchmark bookkeeping, not part of the reference: from now on every step records which elements' G it assigns; orc_num_changed() = how
+ * many of them hold another value after the step than before it (for a step that (re)initialises the search: how many hold a value). */
+void orc_track_changes(orc_t *p, int on) {
+    p->chg_on = on ? 1 : 0;
+    if (p->chg_on && !p->chg_stamp && p->n) {
+        p->chg_stamp = (uint32_t *)calloc(p->n, sizeof(uint32_t));
+        p->chg_g0 = (float *)malloc(p->n * sizeof(float));
+        p->chg_list = (int *)malloc(p->n * sizeof(int));
+    }
+}
+unsigned long orc_num_changed(const orc_t *p) {
+    unsigned long c = 0;
+    if (!p->chg_on) return 0;
+    if (p->chg_n < 0) { for (size_t i = 0; i < p->n; ++i) c += p->g[i] < INFINITY; return c; }      /* the step initialised the search */
+    for (int i = 0; i < p->chg_n; ++i) { const int s = p->chg_list[i]; c += memcmp(&p->g[s], &p->chg_g0[s], sizeof(float)) != 0; }
+    return c;
+}
 int orc_step(orc_t *p) { /* ReplannerBase.h:43-75 */
     if (p->initialize_graph) return ORC_LOOP_FAILURE_NO_GRAPH;
     if (!p->goal_set) return ORC_LOOP_FAILURE_NO_GOAL;
     double t0 = now_ms();
+    if (p->chg_on) { ++p->chg_step; p->chg_n = (p->initialize_search || p->new_goal) ? -1 : 0; }
     refresh_start_nodes(p);
     if (p->initialize_search || p->new_goal) {
         p->num_updated = 0; p->num_expanded = 0;

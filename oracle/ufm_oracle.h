@@ -73,6 +73,9 @@ const float *orc_rhs(const orc_t *p);
 const uint8_t *orc_inmap(const orc_t *p);
 const int32_t *orc_bptr(const orc_t *p); /* level>=1: linear index (DFM: 2 per elem), else NULL */
 
+/* bookkeeping for the benchmark's CPU leg: elements whose G differs after a step (the engine's "cells updated"), see ufm_oracle.c */
+void orc_track_changes(orc_t *p, int on);
+unsigned long orc_num_changed(const orc_t *p);
 unsigned long orc_num_expanded(const orc_t *p);
 unsigned long orc_num_updated(const orc_t *p);
 unsigned long orc_map_size(const orc_t *p);

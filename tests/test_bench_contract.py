@@ -48,6 +48,8 @@ def test_bench_line_single_gpu():
     assert ph["plan_ms"] > 0 and ph["replans_ms"] > 0 and ph["set_map_ms"] > 0 and ph["replans"] == 6
     assert abs(ph["plan_ms"] + ph["replans_ms"] + ph["set_map_ms"] - d["ms_per_step"]) < 0.05 * d["ms_per_step"] + 0.2
     assert ph["plan_cells"] > 0 and ph["replans_cells"] > 0 and cph["plan_ms"] > 0 and cph["replans_ms"] > 0
+    # the replans' cells in BOTH definitions on the CPU leg: the reference's queue pops, and elements whose G differs after the step (the GPU leg's count)
+    assert cph["replans_cells"] > 0 and cph["replans_cells_changed"] > 0
     # ... and the replans' kernel has a roofline entry of its own
     rr = d["roofline_replans"]
     assert rr["bound"] == "hbm" and rr["launches"] == 6 and rr["timed_launches"] >= 1 and rr["avg_launch_us"] > 0
