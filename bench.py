@@ -370,7 +370,7 @@ def run_rank(args, planner_factory=None, factory_label=None):
             p.patch_map_host(h_ptrs[i], top, left, psz, psz)
 
         legs = {"device": (stream, apply_patch)}
-        if dist is None and not rehearsal:
+        if dist is None and not rehearsal and args.patch_inputs != "device":
             legs["host"] = (HostPatches(), apply_patch_host)
         leg = ["host" if "host" in legs else "device"]
 
@@ -488,7 +488,7 @@ def run_rank(args, planner_factory=None, factory_label=None):
         run_warm()
     dt, per_step = ep.timed_episodes(run_one, args.steps, 0, barrier)
     device_leg = None
-    if leg[0] == "host":            # the second leg: the same episodes with the patches resident in HBM (ufm_patch_map_device)
+    if leg[0] == "host" and args.patch_inputs == "both":            # the second leg: the same episodes with the patches resident in HBM (ufm_patch_map_device)
         phases_host = dict(phases)
         leg[0] = "device"
         run_warm()
@@ -554,9 +554,9 @@ def run_rank(args, planner_factory=None, factory_label=None):
             "config": {
                 "workload": "%s, %dx%d cost map (seed %d generator, SURVEY 8d), full plan + %d 31x31 patches with moving start, %s; %s" % (
                     ALGO_LABEL[args.algo], size, size, seed, n_rounds, maps_desc,
-                    "patches handed over from host memory inside the timed region (ufm_patch_map)" if device_leg is not None else
+                    "patches handed over from host memory inside the timed region (ufm_patch_map)" if leg[0] == "host" else
                     "patches resident in HBM (ufm_patch_map_device: the receive buffer of the patch broadcast)"),
-                "patch_inputs": "host" if device_leg is not None else "device",
+                "patch_inputs": leg[0],
                 "algo": args.algo, "size": size, "patches": n_rounds, "heuristic_keys": bool(args.heuristic),
                 "maps_per_gpu": n_local, "maps_total": n_local * world,
                 # one broadcast per replan (round) per rank, warm-up episodes included; 0 without a process group
@@ -690,7 +690,10 @@ def main(argv=None, planner_factory=None, factory_label=None, script=None):
     ap.add_argument("--timeout", type=float, default=1500.0, help="--gpus N self-launch: seconds after which the rank processes are stopped (exit code 124)")
     ap.add_argument("--param", action="append", default=[], metavar="NAME=VALUE",
                     help="scheduler knob for the engine (ufm_set_param / ufm_batch_set_param), e.g. owned_waves=16; for experiments -- the defaults are the product")
-    ap.add_argument("--traffic-json", default="r3_traffic.json", help="file under profiles/ holding the separately collected PMC traffic of the headline run")
+    ap.add_argument("--patch-inputs", default="both", choices=["both", "host", "device"],
+                    help="N = 1, one map per GPU: where the patches come from.  both (default): the episodes with patches from host memory are `value`, a second leg "
+                    "with the patches resident in HBM is `value_device_inputs`; host / device: that leg only (profiles).  With a process group the patches arrive in HBM")
+    ap.add_argument("--traffic-json", default="r4_traffic.json", help="file under profiles/ holding the separately collected PMC traffic of the headline run")
     args = ap.parse_args(argv)
     if args.seed is None:
         args.seed = 1000 if args.batch > 0 else 7

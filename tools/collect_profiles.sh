@@ -9,7 +9,7 @@ mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 mkdir -p build
 [ -x build/traffic_calib ] || /opt/rocm/bin/hipcc -O2 --offload-arch=gfx950 -o build/traffic_calib tools/traffic_calib.hip
-BENCH="python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline"
+BENCH="python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --patch-inputs host"      # (the headline leg: patches from host memory)
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -- $BENCH > $OUT/bench_kernel_trace.log 2>&1
 cp $(find $OUT/kt -name "*kernel_stats.csv" | head -1) $OUT/${TAG}_kernel_stats.csv
 for c in FETCH_SIZE WRITE_SIZE; do

@@ -84,13 +84,30 @@ for i in order:
     by_own.setdefault(int(own[i]), []).append(int(i))
 cur = int(np.argmax(np.where(v_from != 0xFFFFFFFF, v_e, 0)))     # (the last visit that took an activation somebody sent)
 links = []
+inferred = 0
+goal_tile = gx * TY + gy
 while True:
     f, pt = int(v_from[cur]), int(v_pt[cur])
-    if f == 0xFFFFFFFF or f not in by_tile:
-        break
-    cands = [i for i in by_tile[f] if v_s[i] <= pt]
+    cands = [i for i in by_tile.get(f, []) if v_s[i] <= pt] if f != 0xFFFFFFFF else []
     if not cands:
-        break
+        # The record of who sent the activation is missing: own_push() writes the queue word and the diagnostic record with two atomics, and a
+        # visitor that takes the word between them finds no record (round 3: the walk ended there, after ~30 links).  Inferred instead: among the
+        # visits of the eight neighbouring tiles and of the tile itself that ended before this one began, the one that ended last -- a visit sends
+        # its activations at its end, so that is the activation this visit was waiting for.
+        t = int(v_gt[cur]); tx_, ty_ = divmod(t, TY)
+        best = -1
+        for dx in (-1, 0, 1):
+            for dy in (-1, 0, 1):
+                nx_, ny_ = tx_ + dx, ty_ + dy
+                if not (0 <= nx_ < TX and 0 <= ny_ < TY):
+                    continue
+                for i in by_tile.get(nx_ * TY + ny_, []):
+                    if i != cur and v_e[i] and v_e[i] <= v_s[cur] and (best < 0 or v_e[i] > v_e[best]):
+                        best = i
+        if best < 0:
+            break
+        cands, pt = [best], int(v_e[best])
+        inferred += 1
     pred = cands[-1]
     # how much of the wait was the owner busy with other tiles
     busy = same = 0
@@ -115,7 +132,8 @@ while True:
 if not links:
     sys.exit(0)
 la = np.array([(w, sp, b, d, sm) for (_c, _p, w, sp, b, d, sm) in links])
-print("critical path: %d links back from the last visit (ends %.0f us) to a visit starting at %.0f us" % (len(links), v_e.max() / 100.0, v_s[cur] / 100.0))
+print("critical path: %d links back from the last visit (ends %.0f us) to a visit starting at %.0f us (tile %d; the goal's tile is %d); %d links inferred (sender record missing)" % (
+    len(links), v_e.max() / 100.0, v_s[cur] / 100.0, int(v_gt[cur]), goal_tile, inferred))
 print("  per link: activation sent %.1f us after the sender's visit began (its visit lasted %.1f us) + waited %.1f us for its own visit (owner busy with other tiles %.1f us of that)" % (
     la[:, 1].mean(), la[:, 3].mean(), la[:, 0].mean(), la[:, 2].mean()))
 print("  sums: in sender visits %.0f us, waiting %.0f us (owner busy %.0f us; the tile itself still in an earlier visit %.0f us)" % (la[:, 1].sum(), la[:, 0].sum(), la[:, 2].sum(), la[:, 4].sum()))
