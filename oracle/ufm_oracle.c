@@ -13,9 +13,10 @@
  * operation (build with -ffp-contract=off, no fast-math), sqrtf correctly
  * rounded -- the same arithmetic contract the HIP kernels are built to.
  *
- * PARITY PINNING: see ufm_oracle.h -- FD level 0 with heuristic keys, replans
- * and extraction included, is pinned by the reference's recorded mission log
- * (tests/test_reference_mission.py); the rest is "parity unpinned" (no golden
+ * PARITY PINNING: see ufm_oracle.h -- FD with heuristic keys, replans and
+ * extraction included, is pinned by the reference's two recorded mission logs
+ * (both replayed in full in their revision, tests/test_reference_mission.py);
+ * MS-DFM, FD's Type III and whole fields are "parity unpinned" (no golden
  * vectors exist in the reference; the reference is unbuildable in this image),
  * cross-checked against SURVEY.md App. E known answers in tests/test_oracle.py.
  */

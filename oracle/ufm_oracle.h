@@ -6,16 +6,17 @@
  * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may
  * load this library.  The product path (libufm.so, HIP) never links it.
  *
- * PARITY PINNING STATUS: pinned, for ONE planner configuration, on the one output of the reference itself that its tree
- * holds: the console log of a whole mission of its Field D* planner process (level 0, heuristic keys) on its own
- * `noise-trap` bitmap (Tests/Results/noise-trap/planner_opt0.log, an older revision of the sources).  This restatement --
- * planner, replans under a moving start, path extractor -- replays all 134 closed-loop steps of it to the last printed
- * digit of every position, path cost and path length, and its first plan's 8760 expansions (tests/test_reference_mission.py;
- * the first plan of the second log, wall-b, as well).  Everything else -- SG, MS-DFM, the other levels, keys without
- * heuristic, full fields -- is "parity unpinned": cross-checked against the numbers SURVEY.md App. E recorded from a build of
- * the reference with stand-in headers (tests/test_oracle.py), which pins nothing.  The reference ships no golden vectors and
- * cannot be compiled in this image (its three header-only dependencies are un-vendored empty
- * submodules; writing stand-ins for them is not allowed), so there is no oracle/_ref build.
+ * PARITY PINNING STATUS: pinned, for Field D* with heuristic keys, on the two outputs of the reference itself that its tree holds: the
+ * console logs of two whole missions of its Field D* planner process (level 0) on its own bitmaps (Tests/Results/{noise-trap,wall-b}/
+ * planner_opt0.log, written by an older revision of the sources).  In that revision (orc_set_revision(ORC_REV_LOG): start cell by
+ * truncation, update() without the corner nodes on the far map borders -- both identified by search against the logs) this restatement --
+ * planner, replans under a moving start, path extractor -- replays BOTH logs closed-loop in full: 134 + 89 steps, every position, path cost,
+ * path length and "nodes updated" to the last printed digit, and 177 of 178 "nodes expanded"; as the current sources stand it replays the
+ * first log's paths (tests/test_reference_mission.py).  Ablations (orc_set_fd_ablation) say which branches of compute_optimal_cost the logs
+ * cover: B, II, A and Type I; NOT Type III.  Everything else -- MS-DFM, SG's own comparisons, full fields -- is "parity unpinned":
+ * cross-checked against the numbers SURVEY.md App. E recorded from a build of the reference with stand-in headers (tests/test_oracle.py),
+ * which pins nothing.  The reference ships no golden vectors and cannot be compiled in this image (its three header-only dependencies are
+ * un-vendored empty submodules; writing stand-ins for them is not allowed), so there is no oracle/_ref build.
  * The restatement follows the reference sources function by function (citations in
  * ufm_oracle.c / ufm_path_oracle.c).
  */
