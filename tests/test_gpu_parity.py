@@ -787,8 +787,15 @@ def test_back_pointer_view(algo, lvl):
     check[gx, gy] = False                 # the goal has none
     assert (sto[..., 0][check] >= 0).all(), "%d finalised elements without a stored back-pointer" % int((sto[..., 0][check] < 0).sum())
     same = (sto == got).all(axis=2)
-    # (they part where candidates tie, and ties are structural: along a grid edge both triangles over that edge cost g1 + min(c, b))
-    assert same[check].mean() > 0.8, "stored and derived back-pointers agree on only %.3f of the finalised elements" % same[check].mean()
+    # Ties are structural (along a grid edge both triangles over that edge cost g1 + min(c, b)): round 3 kept the lowest code among tied candidates and
+    # the two views parted on 7-8 % of the nodes.  Round 4: the tied candidate the reference's min_rhs<1>() keeps -- the last in neighbors_8 order -- so
+    # for the level-1 node planners stored == derived, element by element.  (SG level 2 derives its back-pointer from another candidate structure,
+    # ShiftedGridPlanner_impl.h:280-303; MS-DFM keeps the lowest code: there the two views may still part at ties.)
+    if (algo, lvl) in (("FD", 1), ("SG", 1)):
+        assert same[check].all(), "stored and derived back-pointers differ on %d of %d finalised elements, first %r" % (
+            int((~same[check]).sum()), int(check.sum()), tuple(np.argwhere(check & ~same)[0]))
+    else:
+        assert same[check].mean() > 0.8, "stored and derived back-pointers agree on only %.3f of the finalised elements" % same[check].mean()
     ey = field.shape[1]
     n_tie = 0
     for x, y in np.argwhere(check):       # the named candidate reproduces the value (all of them; the ties are the interesting ones)

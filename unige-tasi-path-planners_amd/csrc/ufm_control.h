@@ -487,7 +487,7 @@ __device__ void tile_bp(const DevParams &P, int gt, int thr, float *Gs, float *C
         C.load(Cs, lx, ly, q);
         const LaneEval le = eval_quad_w<ALGO>(Gs + (lx + 1) * GP + ly + 1, q, C);
         const float nv = quad_min(le.r);
-        const int b = quad_min_int(bp_byte<ALGO>(le, q, C, le.r == nv));
+        const int bq = quad_min_int(bp_byte<ALGO>(le, q, C, le.r == nv)), b = bq == 0x3FF ? BP_NONE : (bq & 0x1F);
         if (q == 0) P.bp[(size_t)gt * TT + lx * T + ly] = (uint8_t)((x0 + lx == goal_x && y0 + ly == goal_y) ? BP_NONE : b);
     }
     __syncthreads();

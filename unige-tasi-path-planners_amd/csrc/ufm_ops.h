@@ -156,10 +156,16 @@ __device__ __forceinline__ float quad_min(float v) {
 // horizontal one (h = 1); its other vertex p2 is the diagonal node of that cell.  MS-DFM level 0: the stencil (0 orthogonal, 1 diagonal); level 1:
 // (q << 1) | which of the axis's two neighbours (0: -so, 1: +so).  Of several candidates that tie, the lowest code.
 // dep, node planners: which of the two vertices the value depends on -- bit 0: G(p1), bit 1: G(p2) -- by the case compute_optimal_cost took
+// Tied candidates (round 4): the one the reference's min_rhs<1>() would keep -- it walks Graph::neighbors_8 (top, top-left, left, bottom-left, bottom,
+// bottom-right, right, top-right: Graph.cpp:71-85) and lets the LAST tied neighbour win (`if (rhs == cost) bptr = ...`, FD impl:196-208) --, so that the
+// stored byte names the neighbour min_rhs<1>() on the same field names (ufm_read_info == ufm_read_info_derived; round 3 kept the lowest code and the two
+// views parted on the 7-8 % of the nodes whose triangles over one grid edge tie).  bp_ref(code) = that neighbour's position in neighbors_8.
 // (FD impl:292-319, SG :422-436): "g1 + ..." (III, B) leans on p1 alone, "g2 + ..." (I, A) on p2 alone, the interpolated case (II) on both.  With the other
 // vertex at +inf the same case is taken and gives the same value, so: an element is gone exactly when a vertex it depends on is gone (the invalidation of
 // ufm_region.h follows these bits without evaluating anything).  MS-DFM: 3.
 constexpr int BP_NONE = 0xFF;
+// code (q << 1) | h -> index in Graph::neighbors_8 of the node b with RHS(s) = cost(s, b, ccw_neighbor(s, b)): codes 0..7 -> 1 2 0 7 4 3 5 6
+__device__ __forceinline__ int bp_ref(int code) { return (0x65347021u >> (4 * code)) & 7; }
 __device__ __forceinline__ int dep_sg(float g1, float g2, const CellSG &K) {
     const float f = g1 - g2;
     return (f <= 0.0f) ? 1 : ((f * SQRT2F <= K.ccmp) ? 3 : 2);
@@ -186,7 +192,7 @@ __device__ __forceinline__ LaneEval eval_quad_w(const float *ctr, int q, const Q
         float tV, tH;
         if constexpr (ALGO == UFM_ALGO_SG) { tV = tri_sg(e.gV, e.gD, C.k); tH = tri_sg(e.gH, e.gD, C.k); }
         else { tV = tri_fd(e.gV, e.gD, C.k, C.tv); tH = tri_fd(e.gH, e.gD, C.k, C.th); }
-        e.h = tH < tV;
+        e.h = (tH < tV) | ((tH == tV) & (q != 2));      // (a tie inside the lane: the later one in neighbors_8 order -- h = 1 except for cell q = 2)
         e.r = e.h ? tH : tV;
     }
     return e;
@@ -202,7 +208,8 @@ __device__ __forceinline__ int bp_byte(const LaneEval &e, int q, const QuadConst
         t.bp = e.h ? C.th.bp : C.tv.bp; t.cbp = e.h ? C.th.cbp : C.tv.cbp; t.bI = e.h ? C.th.bI : C.tv.bI;
         dep = dep_fd(e.h ? e.gH : e.gV, e.gD, C.k, t);
     }
-    return winner ? ((code << 2) | dep) : 0x3FF;
+    if constexpr (ALGO == ALGO_DFM1) return winner ? ((code << 2) | dep) : 0x3FF;          // (MS-DFM: the lowest code)
+    return winner ? (((7 - bp_ref(code)) << 5) | (code << 2) | dep) : 0x3FF;      // (quad_min_int: the tied candidate latest in neighbors_8 order; the byte = its low 5 bits)
 }
 __device__ __forceinline__ int quad_min_int(int v) {
     v = min(v, __builtin_amdgcn_update_dpp(v, v, 0xB1, 0xF, 0xF, false));   // quad_perm [1,0,3,2]

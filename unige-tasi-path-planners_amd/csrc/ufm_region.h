@@ -547,7 +547,7 @@ __global__ __launch_bounds__(NTHR) void k_replan_region(DevParams P, RegionJobs 
                 C.load_at(cost_at, lx, ly, q, RP);
                 const LaneEval le = eval_quad_w<ALGO, RP>(Gs + (lx + 1) * RP + ly + 1, q, C);
                 const float nv = quad_min(le.r);
-                const int b = quad_min_int(bp_byte<ALGO>(le, q, C, le.r == nv));
+                const int bq = quad_min_int(bp_byte<ALGO>(le, q, C, le.r == nv)), b = bq == 0x3FF ? BP_NONE : (bq & 0x1F);
                 if (q == 0) Bb[lx * RBP + ly] = (uint8_t)((lx == goal_lx && ly == goal_ly) ? BP_NONE : b);
                 if (lane == 0) S.tbp[(pr / TP) * J.nty + pc / TP] = 1;
             }
