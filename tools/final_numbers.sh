@@ -1,7 +1,7 @@
 #!/bin/bash
 # final-code numbers of the BASELINE configurations on one GPU (GPU box): the suite, then bench.py for configs 3 (headline), 2, 4, 5
 # usage: bash tools/final_numbers.sh [directory under gpurun_out/]
-O=gpurun_out/${1:-r3_final}; mkdir -p $O
+O=gpurun_out/${1:-r4_final}; mkdir -p $O
 timeout -k 10 900 python -m pytest tests -m gpu -q > $O/gputests.log 2>&1; echo "tests rc=$?"; tail -2 $O/gputests.log
 timeout -k 10 300 python bench.py --steps 10 --warmup 3 > $O/headline.json 2> $O/headline.err; echo "headline rc=$?"
 timeout -k 10 300 python bench.py --algo SG --size 2048 --seed 1234 --patches 0 --steps 10 --warmup 3 --no-cpu-baseline > $O/config2.json 2> $O/config2.err; echo "config2 rc=$?"

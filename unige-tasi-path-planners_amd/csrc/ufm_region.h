@@ -679,26 +679,32 @@ __global__ __launch_bounds__(NTHR) void k_replan_region(DevParams P, RegionJobs 
         const int npr = __hip_atomic_load(&P.ctr->npark[Q_RAISE], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const int nl = __hip_atomic_load(&P.ctr->cnt[Q_LOWER][J.k_lower % 3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const int npl = __hip_atomic_load(&P.ctr->npark[Q_LOWER], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // (A batch: the other maps' workgroups append to these lists while this one reads them -- a list's length is advanced BEFORE the entry is
+        //  stored (activate(), park_tile()), so a slot below the length may still hold whatever the memory held: an entry is only followed if it
+        //  is a tile of THIS map.  Round 4: the lowering loops used to load the priority of any entry first -- with recycled device memory behind
+        //  the lists that was an intermittent "Memory access fault" of test_batch_with_heuristic_keys..., never seen with fresh (zeroed) memory.
+        //  This map's own entries are complete: its workgroup appended them before the fence above.)
+        auto mine = [&](int gt) { return (unsigned)gt < (unsigned)P.NT && gt / P.NTm == m; };
         for (int i = tid; i < nr; i += NTHR) {
             const int gt = __hip_atomic_load(&P.cand[(size_t)(Q_RAISE * 3 + J.rb.k_raise % 3) * P.NT + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (gt / P.NTm == m) mr = min(mr, prio_read_fresh(P, Q_RAISE, J.rb.k_raise, gt));
+            if (mine(gt)) mr = min(mr, prio_read_fresh(P, Q_RAISE, J.rb.k_raise, gt));
         }
         for (int i = tid; i < npr; i += NTHR) {
             const int gt = __hip_atomic_load(&P.park[(size_t)(Q_RAISE * 2) * P.NT + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (gt / P.NTm == m) mr = min(mr, __hip_atomic_load(&P.pprio[Q_RAISE * P.NT + gt], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+            if (mine(gt)) mr = min(mr, __hip_atomic_load(&P.pprio[Q_RAISE * P.NT + gt], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
         }
         auto lower_key = [&](int gt, int pbits) {      // smallest key an element of the tile can have: priority + hm * dist(start, tile)
-            if (pbits == INFBITS || gt / P.NTm != m) return INFINITY;
+            if (pbits == INFBITS) return INFINITY;
             return __int_as_float(pbits) + (focused ? tile_heuristic(P, m, (gt - gt0) / P.TY, (gt - gt0) % P.TY) : 0.0f);
         };
         float kl = INFINITY;
         for (int i = tid; i < nl; i += NTHR) {
             const int gt = __hip_atomic_load(&P.cand[(size_t)(Q_LOWER * 3 + J.k_lower % 3) * P.NT + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            kl = fminf(kl, lower_key(gt, prio_read_fresh(P, Q_LOWER, J.k_lower, gt)));
+            if (mine(gt)) kl = fminf(kl, lower_key(gt, prio_read_fresh(P, Q_LOWER, J.k_lower, gt)));
         }
         for (int i = tid; i < npl; i += NTHR) {
             const int gt = __hip_atomic_load(&P.park[(size_t)(Q_LOWER * 2) * P.NT + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            kl = fminf(kl, lower_key(gt, __hip_atomic_load(&P.pprio[Q_LOWER * P.NT + gt], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)));
+            if (mine(gt)) kl = fminf(kl, lower_key(gt, __hip_atomic_load(&P.pprio[Q_LOWER * P.NT + gt], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)));
         }
         ml = kl < INFINITY ? __float_as_int(kl) : INFBITS;
         if (mr != INFBITS) atomicMin(&S.m_r, mr);
