@@ -263,6 +263,14 @@ int Engine::alloc(int width, int length) {
     dmalloc(d_scratch, sizeof(int) * (4 * nmaps + 16));
     if (rc != UFM_OK) { release(); return rc; }
     rc = [&]() -> int {
+        // (the lists: a slot that was never written must still read as a tile id -- an in-launch reader may look at a slot its writer has claimed
+        //  but not yet stored, see the end check of k_replan_region)
+        HIPCHK(hipMemsetAsync(P.cand, 0, sizeof(int) * 6 * P.NT, stream));
+        HIPCHK(hipMemsetAsync(P.park, 0, sizeof(int) * 4 * P.NT, stream));
+        HIPCHK(hipMemsetAsync(P.ready, 0, sizeof(int) * P.NT, stream));
+        HIPCHK(hipMemsetAsync(P.tlist, 0, sizeof(int) * P.NT, stream));
+        HIPCHK(hipMemsetAsync(P.slist, 0, sizeof(int) * P.NT, stream));
+        HIPCHK(hipMemsetAsync(P.slist2, 0, sizeof(int) * P.NT, stream));
         HIPCHK(hipMemsetAsync(P.rank, 0, sizeof(int) * P.NT, stream));
         HIPCHK(hipMemsetAsync(P.hint, 0, sizeof(int) * P.NT, stream));
         HIPCHK(hipMemsetAsync(P.spos, 0, sizeof(float) * 2 * nmaps, stream));
