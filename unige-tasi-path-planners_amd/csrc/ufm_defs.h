@@ -93,6 +93,28 @@ constexpr bool DAG = UFM_DAG != 0;
 // borders back.  A visit therefore reads tile + ring + cost window = 14 lines where the row-major
 // layout touched ~60 (two lines per field row, one or two per cost row).
 constexpr int TT = T * T;                                        // floats per tile
+// Which patches a wave of a 16-wave workgroup owns (the block kernel of ufm_region.h; the 16-wave tile visits of k_relax with 16 x 16 tiles).
+// Patch (pr, pc) belongs to the wave with the index ((pr & 3) << 2) | (pc & 3); hardware wave p of the workgroup
+// runs on SIMD p & 3 (read back from HW_ID: tools/replan_timeline.py prints it).  With index = p the four waves of a patch COLUMN class share one
+// SIMD: a front that runs along the rows keeps one SIMD busy and three idle.  UFM_WAVE_PERM: hardware wave p takes the index whose column
+// class is p >> 2 and whose row class is ((p & 3) - 2 * (p >> 2)) & 3, i.e. the patch class (r, c) runs on SIMD (r + 2c) & 3 -- neighbours along
+// a row class two SIMDs apart, along a column one, along either diagonal one or three: no direction of a front lands on a single SIMD.
+#ifndef UFM_WAVE_PERM
+#define UFM_WAVE_PERM 1
+#endif
+__device__ __forceinline__ int wave_index16(int p) {
+#if UFM_WAVE_PERM == 1      // class (r, c) on SIMD (r + 2c) & 3
+    return ((((p & 3) - 2 * (p >> 2)) & 3) << 2) | (p >> 2);
+#elif UFM_WAVE_PERM == 2    // (2r + c) & 3
+    return ((p >> 2) << 2) | (((p & 3) - 2 * (p >> 2)) & 3);
+#elif UFM_WAVE_PERM == 3    // (r + c) & 3
+    return ((((p & 3) - (p >> 2)) & 3) << 2) | (p >> 2);
+#elif UFM_WAVE_PERM == 4    // (r - c) & 3
+    return ((((p & 3) + (p >> 2)) & 3) << 2) | (p >> 2);
+#else
+    return p;
+#endif
+}
 constexpr int RING = (4 * T + 4 + 31) / 32 * 32;                 // floats per ring record (4T+4 used)
 constexpr int RING_TOP = 0, RING_BOT = T, RING_LEFT = 2 * T, RING_RIGHT = 3 * T, RING_CORNER = 4 * T;   // corner order: TL TR BL BR
 constexpr int CTS = ((T + 1) * (T + 1) + 127) / 128 * 128;       // bytes per cost-window record

@@ -135,7 +135,7 @@ template <int ALGO, int MODE>
 __device__ void region_phase(const DevParams &P, const RegionJob &J, float *Gs, const uint8_t *Cb, uint8_t *Bb, RegionShared &S,
                              int thr, float hm, int focused, int goal_lx, int goal_ly) {
     constexpr bool BPRAISE = MODE == MODE_RAISE && !is_dfm<ALGO>;   // invalidation along the stored back-pointers (k_relax)
-    const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
+    const int tid = threadIdx.x, w = wave_index16(tid >> 6), lane = tid & 63;
     const int q = lane & 3, nd = lane >> 2;
     const int nprow = J.ntx * TP, npcol = J.nty * TP;
     unsigned long long wake_sel = 0ull;
@@ -331,10 +331,13 @@ template <int ALGO>
 __global__ __launch_bounds__(NTHR) void k_replan_region(DevParams P, RegionJobs JS, DevCounters *host, unsigned int *flag) {
     __shared__ float Gs[(RN + 2) * RP];
     __shared__ uint8_t Cb[(RN + 1) * RCP];
-    __shared__ uint8_t Bb[RN * RBP];
+    __shared__ __attribute__((aligned(16))) uint8_t Bb[RN * RBP];
     __shared__ RegionShared S;
     __shared__ int s_last;
     __shared__ uint8_t s_pmask[4096];     // change mask of a patch that comes with the job (<= 64 x 64 cells)
+    __shared__ int s_simd[16];               // diagnostics: the SIMD each wave runs on
+    __shared__ unsigned long long s_tb[8];   // diagnostics: the prologue's timeline
+    __shared__ float s_sg[4];             // the start elements' values before the step
     constexpr bool CELLS = is_dfm<ALGO>;
     constexpr int COFF = CELLS ? 0 : 1;
     const int tid = threadIdx.x;
@@ -344,15 +347,102 @@ __global__ __launch_bounds__(NTHR) void k_replan_region(DevParams P, RegionJobs 
     const int rx0 = J.tx0 * T, ry0 = J.ty0 * T, rnx = J.ntx * T, rny = J.nty * T;
 
     const unsigned long long t_begin = wall_clock64();
-    // ---- 0a. the cost bytes of the block (staged first: a patch that comes with the job is applied on top of them) ----
+#define STAMP(k) do { if (tid == 0 && (J.debug & 2)) s_tb[k] = wall_clock64(); } while (0)
+    STAMP(0);
+    if ((tid & 63) == 0 && (J.debug & 2)) s_simd[tid >> 6] = (int)__builtin_amdgcn_s_getreg((1 << 11) | (4 << 6) | 4);   // HW_ID.SIMD_ID
+    const float hm = J.dyn.hm;
+    const int thr = J.dyn.thr, focused = J.dyn.focused;
+    // ---- 0. Everything the kernel needs from memory is asked for FIRST, before anything is waited for (round 4: as five dependent steps --
+    // cost bytes, patch bytes from host memory, the seeding's returning atomics, the start elements' values behind the step bookkeeping's
+    // stores, the tiles -- the prologue took 14 us; `tools/replan_timeline.py`): the bytes of the first patch that comes with the job (host
+    // memory: the longest trip), the start elements' values (for the start's key before the patch), the count of pending seeds.
+    int r_first = -1;                                       // the first rectangle whose patch this kernel applies
+    for (int r = J.rb.nrect - 1; r >= 0; --r) if (J.psrc[r]) r_first = r;
+    // (one patch, applied here, nothing else pending: the common replan.  Its seeding needs no marks and no seed list -- see 0b)
+    const bool one_fused = J.rb.nrect == 1 && r_first == 0 && !J.batch;
+    int pb0[4] = {0, 0, 0, 0};
+    if (r_first >= 0) {
+        const int n0 = J.rb.rect[r_first][3] * J.rb.rect[r_first][4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) { const int e = tid + c * NTHR; if (e < n0) pb0[c] = J.psrc[r_first][e]; }
+    }
+    float sg = INFINITY;
+    {   // (not J.rb.sb.start[tid]: indexing the kernel's arguments by thread is a memory load, waited for with the host's bytes in front of it)
+        const int e = tid == 0 ? J.rb.sb.start[0] : (tid == 1 ? J.rb.sb.start[1] : (tid == 2 ? J.rb.sb.start[2] : (tid == 3 ? J.rb.sb.start[3] : -1)));
+        if (e >= 0) { const int x = e / P.EY; sg = P.G[gaddr(P, m, x, e - x * P.EY)]; }
+    }
+    const int n_pending = P.ctr->scount;
+    // ---- 0a. stage the block: the cost bytes (a patch that comes with the job is applied on top of them), the tiles (contiguous 1 KB each)
+    // with their back-pointer bytes, the 1-element frame around the block ----
+    // (Work is dealt out by wave -- a row piece of 64 cost bytes, a quarter KB of a tile -- so that which row / which tile is the wave's scalar
+    //  arithmetic, and every load of a thread is asked for before the first one is waited for: dealt out element by element, a division and
+    //  a memory round trip per element and thread, this staging took 12 us of the kernel's 160.)
+    STAMP(1);
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6), ln = tid & 63;
     {
         const int crow = rnx + COFF, ccol = rny + COFF;
-        for (int i = tid; i < crow * ccol; i += NTHR) {
-            const int r = i / ccol, c = i - r * ccol;
-            const int cx = rx0 + r - COFF, cy = ry0 + c - COFF;
-            Cb[r * RCP + c] = (cx >= 0 && cy >= 0 && cx < P.L && cy < P.W) ? P.cost[(size_t)m * P.cstride + (size_t)cx * P.W + cy] : (uint8_t)255;
+        constexpr int KP = (RN + 64) / 64, KR = (RN + 16) / 16;          // 64-byte pieces of a row (3), rows per wave (9)
+        const uint8_t *cbase = P.cost + (size_t)m * P.cstride;
+        uint8_t cv[KP * KR];
+#pragma unroll
+        for (int j = 0; j < KP; ++j) {
+            const int c = j * 64 + ln, cy = ry0 + c - COFF;
+            const bool cok = c < ccol && cy >= 0 && cy < P.W;
+#pragma unroll
+            for (int k = 0; k < KR; ++k) {
+                const int r = wv + 16 * k, cx = rx0 + r - COFF;
+                cv[j * KR + k] = 255;
+                if (j * 64 < ccol && r < crow && cx >= 0 && cx < P.L && cok) cv[j * KR + k] = cbase[(size_t)cx * P.W + cy];
+            }
         }
+        constexpr int CPT = TT / 256, KT = RTMAX * RTMAX * CPT / 16;                 // CPT: 64-lane float4 pieces per tile
+        float4 gv[KT];
+        unsigned int bv[KT];
+#pragma unroll
+        for (int k = 0; k < KT; ++k) {
+            const int pc = wv + 16 * k, tl = pc / CPT;
+            if (tl >= ntl) continue;
+            const int ti = tl / J.nty, tj = tl - ti * J.nty, v = (pc - tl * CPT) * 64 + ln;
+            const size_t gt = (size_t)(gt0 + (J.tx0 + ti) * P.TY + J.ty0 + tj);
+            gv[k] = reinterpret_cast<const float4 *>(P.G + gt * TT)[v];
+            bv[k] = reinterpret_cast<const unsigned int *>(P.bp + gt * TT)[v];
+        }
+        // the frame (at most 4 * RN + 4 elements: one per thread)
+        static_assert(4 * RN + 4 <= NTHR, "one frame element per thread");
+        float fv = INFINITY;
+        int fo = -1;
+        if (tid < 2 * (rny + 2) + 2 * rnx) {
+            int hx, hy;
+            if (tid < rny + 2) { hx = -1; hy = tid - 1; }
+            else if (tid < 2 * (rny + 2)) { hx = rnx; hy = tid - (rny + 2) - 1; }
+            else if (tid < 2 * (rny + 2) + rnx) { hx = tid - 2 * (rny + 2); hy = -1; }
+            else { hx = tid - 2 * (rny + 2) - rnx; hy = rny; }
+            const int x = rx0 + hx, y = ry0 + hy;
+            fo = (hx + 1) * RP + hy + 1;
+            if (x >= 0 && y >= 0 && x < P.TX * T && y < P.TY * T) fv = P.G[gaddr(P, m, x, y)];
+        }
+        STAMP(7);
+#pragma unroll
+        for (int j = 0; j < KP; ++j) {
+            const int c = j * 64 + ln;
+#pragma unroll
+            for (int k = 0; k < KR; ++k) {
+                const int r = wv + 16 * k;
+                if (j * 64 < ccol && r < crow && c < ccol) Cb[r * RCP + c] = cv[j * KR + k];
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < KT; ++k) {
+            const int pc = wv + 16 * k, tl = pc / CPT;
+            if (tl >= ntl) continue;
+            const int ti = tl / J.nty, tj = tl - ti * J.nty, e = ((pc - tl * CPT) * 64 + ln) * 4;
+            float *g = &Gs[(ti * T + e / T + 1) * RP + tj * T + e % T + 1];
+            g[0] = gv[k].x; g[1] = gv[k].y; g[2] = gv[k].z; g[3] = gv[k].w;
+            *reinterpret_cast<unsigned int *>(&Bb[(ti * T + e / T) * RBP + tj * T + e % T]) = bv[k];
+        }
+        if (fo >= 0) Gs[fo] = fv;
     }
+    if (tid < 4) s_sg[tid] = sg;
     // ---- 0b. Graph::update (Graph.cpp:36-51) + the seeding of update() for the patches that come with the job -- what k_patch_small does for a
     // patch applied at the call.  Every rectangle lies inside the block (place_job), so the old bytes are in Cb: compare there, write the changed
     // ones to the raster, to the cost windows and to Cb; the change mask stays in LDS.  In the order the patches were handed over (they may overlap).
@@ -361,35 +451,60 @@ __global__ __launch_bounds__(NTHR) void k_replan_region(DevParams P, RegionJobs 
         const int *qr = J.rb.rect[r];                       // {map, x, y, w, h}
         const int px = qr[1], py = qr[2], pw = qr[3], ph = qr[4];
         __syncthreads();                                    // Cb staged / the previous rectangle's seeds read
-        for (int e = tid; e < pw * ph; e += NTHR) {
+        STAMP(2);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int e = tid + c * NTHR;
+            if (e >= pw * ph) continue;
             const int i = e / pw, j = e - i * pw;
             uint8_t *cb = &Cb[(px + i - rx0 + COFF) * RCP + (py + j - ry0 + COFF)];
-            const uint8_t nv = J.psrc[r][e];
+            const uint8_t nv = (r == r_first) ? (uint8_t)pb0[c] : J.psrc[r][e];
             const uint8_t ch = *cb != nv;
             s_pmask[e] = ch;
             if (ch) { *cb = nv; P.cost[(size_t)m * P.cstride + (size_t)(px + i) * P.W + (py + j)] = nv; cost_window_store(P, m, px + i, py + j, nv); }
         }
         __syncthreads();
+        STAMP(3);
         const int ne = CELLS ? pw * ph : (pw + 1) * (ph + 1);
-        for (int base = 0; base < ne; base += NTHR) patch_seed<!CELLS>(P, m, s_pmask, px, py, pw, ph, base + tid);
+        if (one_fused) {
+            // num_nodes_updated (FD impl:138, DFM impl:109): the elements a changed cell touches.  One patch, nothing else pending: no element can
+            // have been counted already (the marks, which are for that, are all clear between steps and stay clear), and every seeded tile lies
+            // inside the block (no seed list).  Counted per wave, one atomic each.
+            const int ew = CELLS ? pw : pw + 1;
+            int cnt = 0;
+            for (int e = tid; e < ne; e += NTHR) {
+                const int i = e / ew, j = e - i * ew;
+                bool ch;
+                if (!CELLS) ch = (i > 0 && j > 0 && s_pmask[(i - 1) * pw + j - 1]) || (i > 0 && j < pw && s_pmask[(i - 1) * pw + j]) ||
+                                 (i < ph && j > 0 && s_pmask[i * pw + j - 1]) || (i < ph && j < pw && s_pmask[i * pw + j]);
+                else ch = s_pmask[i * pw + j];
+                cnt += ch ? 1 : 0;
+            }
+            for (int o = 32; o; o >>= 1) cnt += __shfl_xor(cnt, o);
+            if ((tid & 63) == 0 && cnt) atomicAdd(&P.num_updated[m], (unsigned int)cnt);
+        } else {
+            for (int base = 0; base < ne; base += NTHR) patch_seed<!CELLS>(P, m, s_pmask, px, py, pw, ph, base + tid);
+        }
     }
     if (J.rb.nrect && J.psrc[J.rb.nrect - 1]) __syncthreads();      // (the seeds' list entries and counts are read below)
-    // ---- 0. what k_replan_begin does: step bookkeeping, mark reset, the seeds, the invalidation bound ----
+    STAMP(4);
+    // ---- 0c. what k_replan_begin does: step bookkeeping, mark reset, the seeds, the invalidation bound ----
     if (tid == 0 && !J.batch) *P.dyn = J.dyn;      // (a batch: the host has put them in place before the launch -- other workgroups read them too)
     if (!J.batch) step_begin(P, J.rb.sb);
-    for (int r = 0; r < J.rb.nrect; ++r) {
-        const int *qr = J.rb.rect[r];
-        for (int e = tid; e < (qr[3] + 1) * (qr[4] + 1); e += NTHR) clear_mark(P, qr[0], qr[1], qr[2], qr[3], qr[4], e);
-    }
+    if (!one_fused)
+        for (int r = 0; r < J.rb.nrect; ++r) {
+            const int *qr = J.rb.rect[r];
+            for (int e = tid; e < (qr[3] + 1) * (qr[4] + 1); e += NTHR) clear_mark(P, qr[0], qr[1], qr[2], qr[3], qr[4], e);
+        }
     for (int i = tid; i < (int)(sizeof(RegionShared) / sizeof(int)); i += NTHR) reinterpret_cast<int *>(&S)[i] = 0;
     __syncthreads();
+    STAMP(5);
     for (int i = tid; i < 2 * RTMAX * RTMAX; i += NTHR) (&S.dprio[0][0])[i] = INFBITS;
     for (int i = tid; i < RFRAME; i += NTHR) { S.actL[i] = INFBITS; S.actR[i] = INFBITS; }
     if (tid == 0) { S.rmin = INFBITS; S.m_r = INFBITS; }
-    const float hm = J.dyn.hm;
-    const int thr = J.dyn.thr, focused = J.dyn.focused;
     {   // pending seeds of this map (all consumed): tiles inside the block are handled here, any other goes to the queue
-        const int n = P.ctr->scount;
+        // (n_pending was read before the patches of this job were seeded: the general seeding above appends to the list)
+        const int n = one_fused ? n_pending : P.ctr->scount;
         for (int i = tid; i < n; i += NTHR) {
             const int gt = P.slist[i];
             if (gt / P.NTm != m) continue;
@@ -398,11 +513,11 @@ __global__ __launch_bounds__(NTHR) void k_replan_region(DevParams P, RegionJobs 
             if (tx < J.tx0 || tx >= J.tx0 + J.ntx || ty < J.ty0 || ty >= J.ty0 + J.nty) activate(P, Q_RAISE, J.rb.k_raise, gt, 0);
         }
         __syncthreads();
+        STAMP(6);
         if (tid == 0) {
             if (!J.batch) { P.ctr->scount = 0; P.ctr->done = 0; }   // (a batch: the last workgroup, when everybody has read the list)
-            const float b0 = start_bound(P, m);            // the start's key before the patch (the step's start is in place)
-            S.B0 = b0;
-            S.rbound = focused ? b0 + J.rb.band : INFINITY;
+            // the start's key before the patch (start_bound(), from the values asked for at the top)
+            float b0 = 0.0f;
             bool in = false;
             for (int i = 0; i < 4; ++i) {
                 const int e = J.rb.sb.start[i];
@@ -410,30 +525,17 @@ __global__ __launch_bounds__(NTHR) void k_replan_region(DevParams P, RegionJobs 
                 if (e < 0) continue;
                 const int x = e / P.EY, y = e - x * P.EY;
                 S.sdist[i] = hm * hypotf(J.rb.sb.sx - (float)x, J.rb.sb.sy - (float)y);
+                if (s_sg[i] < INFINITY) b0 = fmaxf(b0, s_sg[i] + S.sdist[i]);
                 if (x >= rx0 && x < rx0 + rnx && y >= ry0 && y < ry0 + rny) { S.soff[i] = (x - rx0 + 1) * RP + (y - ry0 + 1); in = true; }
             }
+            b0 = b0 > 0.0f ? b0 : INFINITY;
+            S.B0 = b0;
+            S.rbound = focused ? b0 + J.rb.band : INFINITY;
             S.any_start_in = in ? 1 : 0;
         }
     }
 
-    if (tid == 0) { S.tstamp[0] = t_begin; S.tstamp[1] = wall_clock64(); }
-    // ---- 1. stage the block: tiles (contiguous 1 KB each), the 1-element frame around it, the cost bytes ----
-    for (int i = tid; i < ntl * TT; i += NTHR) {
-        const int tl = i / TT, e = i - tl * TT, ti = tl / J.nty, tj = tl - ti * J.nty;
-        const int gt = gt0 + (J.tx0 + ti) * P.TY + J.ty0 + tj;
-        Gs[(ti * T + e / T + 1) * RP + tj * T + e % T + 1] = P.G[(size_t)gt * TT + e];
-        Bb[(ti * T + e / T) * RBP + tj * T + e % T] = P.bp[(size_t)gt * TT + e];
-    }
-    for (int i = tid; i < 2 * (rny + 2) + 2 * rnx; i += NTHR) {
-        int hx, hy;
-        if (i < rny + 2) { hx = -1; hy = i - 1; }
-        else if (i < 2 * (rny + 2)) { hx = rnx; hy = i - (rny + 2) - 1; }
-        else if (i < 2 * (rny + 2) + rnx) { hx = i - 2 * (rny + 2); hy = -1; }
-        else { hx = i - 2 * (rny + 2) - rnx; hy = rny; }
-        const int x = rx0 + hx, y = ry0 + hy;
-        const bool in = x >= 0 && y >= 0 && x < P.TX * T && y < P.TY * T;
-        Gs[(hx + 1) * RP + hy + 1] = in ? P.G[gaddr(P, m, x, y)] : INFINITY;
-    }
+    if (tid == 0) { S.tstamp[0] = t_begin; S.tstamp[1] = wall_clock64(); S.tstamp[2] = S.tstamp[1]; }
     // the seeds: every patch that holds an element of a consumed rectangle (a superset of the changed cells' elements;
     // a sweep that finds nothing to do costs a fraction of a microsecond)
     __syncthreads();
@@ -450,7 +552,6 @@ __global__ __launch_bounds__(NTHR) void k_replan_region(DevParams P, RegionJobs 
             S.traised[(pr / TP) * J.nty + pc / TP] = 1;      // a seeded tile is invalidated without a bound (the launch chain queues seeds with priority 0)
         }
     }
-    if (tid == 0) S.tstamp[2] = wall_clock64();
     if (tid < 4) S.swas[tid] = (S.soff[tid] >= 0 && Gs[S.soff[tid]] < INFINITY) ? 1 : 0;
     __syncthreads();
     const int goal_lx = P.goal[2 * m] - rx0, goal_ly = P.goal[2 * m + 1] - ry0;
@@ -531,7 +632,7 @@ __global__ __launch_bounds__(NTHR) void k_replan_region(DevParams P, RegionJobs 
     // the patches around it -- a neighbour's value may be what it was and still come from another triangle now --, evaluated once more on the
     // values as they stand, the arg-min kept.  (MS-DFM level 0 has none.)
     {
-        const int w = tid >> 6, lane = tid & 63, q = lane & 3, nd = lane >> 2;
+        const int w = wave_index16(tid >> 6), lane = tid & 63, q = lane & 3, nd = lane >> 2;
         const int nprow = J.ntx * TP, npcol = J.nty * TP;
         auto cost_at = [=](int r, int c) { const int b = Cb[r * RCP + c]; return b >= thr ? INFINITY : (float)b; };
         for (int wd = 0; wd < RWW; ++wd) {
@@ -563,29 +664,28 @@ __global__ __launch_bounds__(NTHR) void k_replan_region(DevParams P, RegionJobs 
         if (tj < 0) return 2 * (J.nty + 2) + ti;                     // left column
         return 2 * (J.nty + 2) + J.ntx + ti;                         // right column
     };
-    constexpr int PER = (RTMAX * RTMAX * TT + NTHR - 1) / NTHR;      // elements per thread (25)
+    constexpr int PER = (RTMAX * RTMAX * TT + NTHR - 1) / NTHR;      // elements per thread (16)
+    static_assert(NTHR == 1024 && TT % 256 == 0 && RBP % 4 == 0, "the block kernel deals its staging and write-back out by wave");
     float init[PER];
     int n_exp = 0;
     // (the values HBM holds, for all of this thread's elements at once: asked for one after the other, each in front of its
-    //  comparison, they were nine memory round trips in a row)
+    //  comparison, they were nine memory round trips in a row.  A wave's 64 elements lie in one tile: which tile is scalar arithmetic.)
 #pragma unroll
     for (int it = 0; it < PER; ++it) {
-        const int i = tid + it * NTHR;
+        const int i = tid + it * NTHR, tl = __builtin_amdgcn_readfirstlane(i / TT);
         init[it] = 0.0f;
-        if (i < ntl * TT && S.tbp[i / TT]) {      // the renewed back-pointers of the tile (a patch next to a changed one may lie in an unchanged tile)
-            const int tl = i / TT, e = i - tl * TT, ti = tl / J.nty, tj = tl - ti * J.nty;
-            P.bp[(size_t)(gt0 + (J.tx0 + ti) * P.TY + J.ty0 + tj) * TT + e] = Bb[(ti * T + e / T) * RBP + tj * T + e % T];
-        }
-        if (i < ntl * TT && S.tflag[i / TT]) {
-            const int tl = i / TT, ti = tl / J.nty, tj = tl - ti * J.nty;
-            init[it] = P.G[(size_t)(gt0 + (J.tx0 + ti) * P.TY + J.ty0 + tj) * TT + (i - tl * TT)];
-        }
+        if (tl >= ntl) continue;
+        const int e = i - tl * TT, ti = tl / J.nty, tj = tl - ti * J.nty;
+        const size_t gt = (size_t)(gt0 + (J.tx0 + ti) * P.TY + J.ty0 + tj);
+        // the renewed back-pointers of the tile (a patch next to a changed one may lie in an unchanged tile)
+        if (S.tbp[tl]) P.bp[gt * TT + e] = Bb[(ti * T + e / T) * RBP + tj * T + e % T];
+        if (S.tflag[tl]) init[it] = P.G[gt * TT + e];
     }
 #pragma unroll
     for (int it = 0; it < PER; ++it) {
-        const int i = tid + it * NTHR;
-        if (i >= ntl * TT) continue;
-        const int tl = i / TT, e = i - tl * TT, ti = tl / J.nty, tj = tl - ti * J.nty;
+        const int i = tid + it * NTHR, tl = __builtin_amdgcn_readfirstlane(i / TT);
+        if (tl >= ntl) continue;
+        const int e = i - tl * TT, ti = tl / J.nty, tj = tl - ti * J.nty;
         if (!S.tflag[tl]) continue;                                         // nothing was applied in this tile
         const int tx = J.tx0 + ti, ty = J.ty0 + tj, gt = gt0 + tx * P.TY + ty;
         const int io_r = e / T, io_c = e % T;
@@ -752,6 +852,8 @@ __global__ __launch_bounds__(NTHR) void k_replan_region(DevParams P, RegionJobs 
                 for (int i = 0; i < 8; ++i) d[22 + i] = S.dbg[i];
                 S.tstamp[6] = wall_clock64();
                 for (int i = 1; i < 7; ++i) d[30 + i] = (int)(S.tstamp[i] - S.tstamp[0]);
+                for (int i = 1; i < 8; ++i) d[40 + i] = (int)(s_tb[i] - s_tb[0]);
+                for (int i = 0; i < 16; ++i) d[50 + i] = s_simd[i];
             }
         }
         __syncthreads();

@@ -66,7 +66,9 @@ __global__ __launch_bounds__(OWNK == 2 ? NTHR / 2 : NTHR, UFM_RELAX_WAVES) void 
 
     const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
     const int q = lane & 3, nd = lane >> 2;                    // quad lane, node within the 4x4 patch
-    const int wr = w >> 2, wc = w & 3;                         // the wave's 8x8 region = 2x2 patches
+    // (wp: the wave's index as an owner of patches -- wave_index16(): which SIMD a patch class runs on)
+    const int wp = (NWV == 16 && PR == 1) ? wave_index16(w) : w;
+    const int wr = wp >> 2, wc = wp & 3;                       // the wave's 8x8 region = 2x2 patches
     const int io_r = tid / T, io_c = tid % T;                  // HBM mapping (threads tid < T*T)
     const bool io_on = tid < T * T;
     constexpr int Q = (MODE == MODE_LOWER) ? Q_LOWER : Q_RAISE;
@@ -615,7 +617,7 @@ __global__ __launch_bounds__(OWNK == 2 ? NTHR / 2 : NTHR, UFM_RELAX_WAVES) void 
 #endif
         for (;;) {
             int bits = 0;
-            if (lane == 0) bits = atomicExch(&s_wake[w], 0);
+            if (lane == 0) bits = atomicExch(&s_wake[wp], 0);
             bits = __builtin_amdgcn_readfirstlane(bits);
             bool vote = __hip_atomic_load(&s_giveup, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != 0;
             if (bits && !vote) {
@@ -690,7 +692,7 @@ __global__ __launch_bounds__(OWNK == 2 ? NTHR / 2 : NTHR, UFM_RELAX_WAVES) void 
                     if (lane == 0) atomicAdd(&g_sstat[8 + min(cnt[j] - sst_c0, 16) - 1], 1ull);
 #endif
                     if (again && lane == 0)              // burst cap: leave the rest to the next take
-                        __hip_atomic_fetch_or(&s_wake[w], 1 << j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        __hip_atomic_fetch_or(&s_wake[wp], 1 << j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                     if constexpr (EARLY) if (!(P.own_flags & 2)) {
                         // Early hand-off.  A plan is a chain of dependent tile visits: the next tile on a front's way can
                         // only start when this visit has been written back, although its inputs -- this tile's far border -- are usually
@@ -705,7 +707,7 @@ __global__ __launch_bounds__(OWNK == 2 ? NTHR / 2 : NTHR, UFM_RELAX_WAVES) void 
                         const int w_ = t_ >> 6, l_ = t_ & 63;
                         int pr_, pc_;
                         if constexpr (SKEW) { pc_ = j ? (w_ < 2 ? 3 : (w_ >> 1)) : (w_ < 4 ? 0 : (w_ >> 1) - 1); pr_ = (w_ - 2 * pc_) & 7; }
-                        else { pr_ = (w_ >> 2) * PR + j / PR; pc_ = (w_ & 3) * PR + j % PR; }
+                        else { const int wq_ = (NWV == 16 && PR == 1) ? wave_index16(w_) : w_; pr_ = (wq_ >> 2) * PR + j / PR; pc_ = (wq_ & 3) * PR + j % PR; }
                         if ((pr_ == 0 || pr_ == PT - 1 || pc_ == 0 || pc_ == PT - 1) && !((P.own_flags & 4) && (ew_done & (1 << j)))) {      // (wave-uniform)
                             const int lx = pr_ * 4 + (l_ >> 4), ly = pc_ * 4 + ((l_ >> 2) & 3);
                             const bool onb = (lx == 0) | (lx == T - 1) | (ly == 0) | (ly == T - 1);
@@ -731,7 +733,7 @@ __global__ __launch_bounds__(OWNK == 2 ? NTHR / 2 : NTHR, UFM_RELAX_WAVES) void 
                 continue;
             }
             if (!vote) {                                 // nothing to do: idle until woken or all idle
-                if (bits && lane == 0) __hip_atomic_fetch_or(&s_wake[w], bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                if (bits && lane == 0) __hip_atomic_fetch_or(&s_wake[wp], bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 if (lane == 0) atomicAdd(&s_idle, 1);
                 UFM_WREC(3, 0);
                 int polls = 0;
@@ -750,7 +752,7 @@ __global__ __launch_bounds__(OWNK == 2 ? NTHR / 2 : NTHR, UFM_RELAX_WAVES) void 
                     }
                     if (__hip_atomic_load(&s_idle, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >= NWV ||
                         __hip_atomic_load(&s_giveup, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != 0) { vote = true; break; }
-                    if (__hip_atomic_load(&s_wake[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != 0) {
+                    if (__hip_atomic_load(&s_wake[wp], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != 0) {
                         if (lane == 0) atomicSub(&s_idle, 1);
                         UFM_WREC(4, 0);
                         break;
@@ -758,12 +760,12 @@ __global__ __launch_bounds__(OWNK == 2 ? NTHR / 2 : NTHR, UFM_RELAX_WAVES) void 
                 }
                 if (!vote) continue;
             } else if (bits && lane == 0) {
-                __hip_atomic_fetch_or(&s_wake[w], bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // put back what was taken
+                __hip_atomic_fetch_or(&s_wake[wp], bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // put back what was taken
             }
             // vote: everybody arrives first, then the wake bits are stable
             UFM_WREC(5, 0);
             __syncthreads();
-            const int work = __syncthreads_or(__hip_atomic_load(&s_wake[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != 0);
+            const int work = __syncthreads_or(__hip_atomic_load(&s_wake[wp], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != 0);
             const int gave_up = __hip_atomic_load(&s_giveup, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             if (gave_up || !work) { conv = !gave_up; break; }
             if (tid == 0) s_idle = 0;
