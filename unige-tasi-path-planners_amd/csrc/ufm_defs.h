@@ -102,6 +102,18 @@ constexpr int TT = T * T;                                        // floats per t
 #ifndef UFM_WAVE_PERM
 #define UFM_WAVE_PERM 1
 #endif
+// ... and of an 8-wave visit (the wave with index w owns the two patches with (pr + 2 pc) mod 8 = w): UFM_WAVE_PERM8
+#ifndef UFM_WAVE_PERM8
+#define UFM_WAVE_PERM8 1
+#endif
+__device__ __forceinline__ int wave_index8(int p) {
+#if UFM_WAVE_PERM8 == 1      // index w on SIMD ((w >> 1) + 2 (w & 1)) & 3: the patches of a row AND of a column on four SIMDs
+    const int s = p & 3;
+    return (p >> 2) ? 2 * ((s + 2) & 3) + 1 : 2 * s;
+#else
+    return p;
+#endif
+}
 __device__ __forceinline__ int wave_index16(int p) {
 #if UFM_WAVE_PERM == 1      // class (r, c) on SIMD (r + 2c) & 3
     return ((((p & 3) - 2 * (p >> 2)) & 3) << 2) | (p >> 2);

@@ -67,7 +67,7 @@ __global__ __launch_bounds__(OWNK == 2 ? NTHR / 2 : NTHR, UFM_RELAX_WAVES) void 
     const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
     const int q = lane & 3, nd = lane >> 2;                    // quad lane, node within the 4x4 patch
     // (wp: the wave's index as an owner of patches -- wave_index16(): which SIMD a patch class runs on)
-    const int wp = (NWV == 16 && PR == 1) ? wave_index16(w) : w;
+    const int wp = (NWV == 16 && PR == 1) ? wave_index16(w) : (SKEW ? wave_index8(w) : w);
     const int wr = wp >> 2, wc = wp & 3;                       // the wave's 8x8 region = 2x2 patches
     const int io_r = tid / T, io_c = tid % T;                  // HBM mapping (threads tid < T*T)
     const bool io_on = tid < T * T;
@@ -575,7 +575,7 @@ __global__ __launch_bounds__(OWNK == 2 ? NTHR / 2 : NTHR, UFM_RELAX_WAVES) void 
 #pragma unroll
         for (int j = 0; j < PPWK; ++j) {
             int pr_, pc_;                                      // the wave's patch j in the PT x PT patch grid
-            if constexpr (SKEW) { pc_ = j ? (w < 2 ? 3 : (w >> 1)) : (w < 4 ? 0 : (w >> 1) - 1); pr_ = (w - 2 * pc_) & 7; }
+            if constexpr (SKEW) { pc_ = j ? (wp < 2 ? 3 : (wp >> 1)) : (wp < 4 ? 0 : (wp >> 1) - 1); pr_ = (wp - 2 * pc_) & 7; }
             else { pr_ = wr * PR + j / PR; pc_ = wc * PR + j % PR; }
             const int lx = pr_ * 4 + (nd >> 2), ly = pc_ * 4 + (nd & 3);
             C[j].load(Cs, lx, ly, q);
@@ -706,7 +706,7 @@ __global__ __launch_bounds__(OWNK == 2 ? NTHR / 2 : NTHR, UFM_RELAX_WAVES) void 
                         asm volatile("" : "+v"(t_));     // (nothing of this is to be computed ahead of the sweeps and carried through them)
                         const int w_ = t_ >> 6, l_ = t_ & 63;
                         int pr_, pc_;
-                        if constexpr (SKEW) { pc_ = j ? (w_ < 2 ? 3 : (w_ >> 1)) : (w_ < 4 ? 0 : (w_ >> 1) - 1); pr_ = (w_ - 2 * pc_) & 7; }
+                        if constexpr (SKEW) { const int wq_ = wave_index8(w_); pc_ = j ? (wq_ < 2 ? 3 : (wq_ >> 1)) : (wq_ < 4 ? 0 : (wq_ >> 1) - 1); pr_ = (wq_ - 2 * pc_) & 7; }
                         else { const int wq_ = (NWV == 16 && PR == 1) ? wave_index16(w_) : w_; pr_ = (wq_ >> 2) * PR + j / PR; pc_ = (wq_ & 3) * PR + j % PR; }
                         if ((pr_ == 0 || pr_ == PT - 1 || pc_ == 0 || pc_ == PT - 1) && !((P.own_flags & 4) && (ew_done & (1 << j)))) {      // (wave-uniform)
                             const int lx = pr_ * 4 + (l_ >> 4), ly = pc_ * 4 + ((l_ >> 2) & 3);
