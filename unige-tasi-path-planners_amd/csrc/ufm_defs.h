@@ -75,6 +75,18 @@ constexpr int NTHR = 1024;     // 16 waves; four lanes per node, each wave owns 
 #ifndef UFM_EARLY_POLLS
 #define UFM_EARLY_POLLS 6      // ... its queue words follow after this many looks of the idle wave at its wake bits (the stores have landed by then)
 #endif
+// Issue priority (s_setprio): waves that sweep, stage or write back run above waves that only look -- an idle wave of a visit at its wake bits,
+// a workgroup without a tile at the queue words -- so that on a SIMD the looks do not take issue slots from the wave on the chain.  In the 8-wave form
+// (two visits per CU; FD 4096^2 plan kernel 14.0 -> 13.6 ms, MS-DFM 2048^2 11.9 -> 11.7); with 16 waves per visit, whose idle waves also fetch the tile's
+// new inputs during the visit (in-visit refresh), it costs visits: SG 2048^2 51 k -> 55 k, 5.25 -> 5.4 ms -- not there.
+#ifndef UFM_VISIT_PRIO
+#define UFM_VISIT_PRIO 3
+#endif
+#if UFM_VISIT_PRIO
+#define UFM_SETPRIO(x) __builtin_amdgcn_s_setprio(x)
+#else
+#define UFM_SETPRIO(x) do {} while (0)
+#endif
 #ifndef UFM_IDLE_SLEEP
 #define UFM_IDLE_SLEEP 4
 #endif

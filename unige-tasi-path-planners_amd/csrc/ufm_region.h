@@ -19,10 +19,20 @@
 // A sweep budget bounds every wave (livelock guard): what is still dirty when it runs out goes to the queues too.
 
 #ifndef UFM_REGION_IDLE_SLEEP_RAISE
-#define UFM_REGION_IDLE_SLEEP_RAISE 16    // ... in the node planners' invalidation phase, whose sweeps are a few loads and a compare
+#define UFM_REGION_IDLE_SLEEP_RAISE 8    // ... in the node planners' invalidation phase, whose sweeps are a few loads and a compare
+#endif
+// Waves that sweep run at a higher issue priority than waves that look for work (s_setprio): the looks of the idle waves of a SIMD do not
+// take the issue slots of the one that is on the chain
+#ifndef UFM_REGION_PRIO
+#define UFM_REGION_PRIO 2
+#endif
+#if UFM_REGION_PRIO
+#define UFM_REGION_SETPRIO(x) __builtin_amdgcn_s_setprio(x)
+#else
+#define UFM_REGION_SETPRIO(x) do {} while (0)
 #endif
 #ifndef UFM_REGION_IDLE_SLEEP
-#define UFM_REGION_IDLE_SLEEP 16          // an idle wave of the block kernel looks at its wake words this often (x 64 clocks): 1 / 4 / 16 / 32 / 64 -> 100 replans 18.9 / 18.0 / 17.6 / 17.6 / 17.8 ms (the looks of twelve idle waves take issue slots and LDS cycles from the four that sweep)
+#define UFM_REGION_IDLE_SLEEP 8          // an idle wave of the block kernel looks at its wake words this often (x 64 clocks): 1 / 4 / 16 / 32 / 64 -> 100 replans 18.9 / 18.0 / 17.6 / 17.6 / 17.8 ms (the looks of twelve idle waves take issue slots and LDS cycles from the four that sweep)
 #endif
 constexpr int RTMAX = 128 / T;            // block edge in tiles (8 for 16 x 16 tiles: field 71 KB + cost bytes 17 KB + back-pointer codes 16 KB of the CU's 160 KB LDS)
 constexpr int RN = RTMAX * T;             // ... in elements (160)
@@ -161,6 +171,7 @@ __device__ void region_phase(const DevParams &P, const RegionJob &J, float *Gs, 
     const float rb_phase = S.rbound + J.slack;
     // words of this wave that can hold a bit at all (a block smaller than RTMAX x RTMAX leaves the upper ones empty)
     const int nwords = min(RWW, (((nprow + 3) / 4 - 1) * RPW + (npcol + 3) / 4 + 31) / 32);
+    UFM_REGION_SETPRIO(UFM_REGION_PRIO);
     for (;;) {
         bool took = false;
         bool vote = __hip_atomic_load(&S.giveup, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != 0;
@@ -297,6 +308,7 @@ __device__ void region_phase(const DevParams &P, const RegionJob &J, float *Gs, 
         if (took && !vote) continue;
         if (!vote) {                                                         // nothing to do: idle until woken or all idle
             if (lane == 0) atomicAdd(&S.idle, 1);
+            UFM_REGION_SETPRIO(0);
             for (;;) {
                 __builtin_amdgcn_s_sleep((MODE == MODE_RAISE && !is_dfm<ALGO>) ? UFM_REGION_IDLE_SLEEP_RAISE : UFM_REGION_IDLE_SLEEP);
                 // (all loads first, then the decisions: one LDS round trip per look)
@@ -308,6 +320,7 @@ __device__ void region_phase(const DevParams &P, const RegionJob &J, float *Gs, 
                 if (idle_now >= 16 || gave_up_now != 0) { vote = true; break; }
                 if (any) { if (lane == 0) atomicSub(&S.idle, 1); break; }
             }
+            UFM_REGION_SETPRIO(UFM_REGION_PRIO);
             if (!vote) continue;
         }
         // vote: everybody arrives first, then the wake bits are stable
@@ -321,6 +334,7 @@ __device__ void region_phase(const DevParams &P, const RegionJob &J, float *Gs, 
         if (tid == 0) S.idle = 0;
         __syncthreads();
     }
+    UFM_REGION_SETPRIO(0);
     if (lane == 0 && my_sweeps) atomicAdd(&S.sweeps, my_sweeps);
     __syncthreads();
     if (tid == 0) S.idle = 0;

@@ -66,6 +66,7 @@ __global__ __launch_bounds__(OWNK == 2 ? NTHR / 2 : NTHR, UFM_RELAX_WAVES) void 
 
     const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
     const int q = lane & 3, nd = lane >> 2;                    // quad lane, node within the 4x4 patch
+    if constexpr (NWV == 8) UFM_SETPRIO(UFM_VISIT_PRIO);
     // (wp: the wave's index as an owner of patches -- wave_index16(): which SIMD a patch class runs on)
     const int wp = (NWV == 16 && PR == 1) ? wave_index16(w) : (SKEW ? wave_index8(w) : w);
     const int wr = wp >> 2, wc = wp & 3;                       // the wave's 8x8 region = 2x2 patches
@@ -155,6 +156,7 @@ __global__ __launch_bounds__(OWNK == 2 ? NTHR / 2 : NTHR, UFM_RELAX_WAVES) void 
         if constexpr (OWN) {
             if (own_next >= 0 && s_own[3] >= INFBITS) own_next = -1;   // chosen ahead from the older copy of the words, but the take failed
             if (tid == 0 && s_own[1] >= 0) { s_own[0] = s_own[1]; s_own[1] = -1; }   // (at most one mark waits: own_commit ran since)
+            if (NWV == 8 && own_next < 0) UFM_SETPRIO(0);                  // (looking for work: behind the waves of the CU's other visit)
             while (own_next < 0) {                             // nothing was taken ahead: look, wait, look again
                 __syncthreads();                               // LDS of the previous visit / round is free
                 // the other owners' hints.  (UFM_LEAN_LOOKS: a sample of them, another one at every look and in an order of this workgroup's own --
@@ -255,6 +257,7 @@ __global__ __launch_bounds__(OWNK == 2 ? NTHR / 2 : NTHR, UFM_RELAX_WAVES) void 
                 }
             }
             if (own_next < 0) break;
+            if constexpr (NWV == 8) UFM_SETPRIO(UFM_VISIT_PRIO);
             { const int o_ = own_next / P.own_slots; int m_, tx_, ty_; gt_own = own_tile(P, o_, own_next - o_ * P.own_slots, m_, tx_, ty_); }
             if (tid == 0) s_own[1] = own_next;
             own_slot_now = own_next;
@@ -737,6 +740,7 @@ __global__ __launch_bounds__(OWNK == 2 ? NTHR / 2 : NTHR, UFM_RELAX_WAVES) void 
                 if (lane == 0) atomicAdd(&s_idle, 1);
                 UFM_WREC(3, 0);
                 int polls = 0;
+                if constexpr (NWV == 8) UFM_SETPRIO(0);         // (an idle wave's looks: behind the waves that sweep)
                 for (;;) {
                     __builtin_amdgcn_s_sleep(UFM_IDLE_SLEEP);
                     ++polls;
@@ -758,6 +762,7 @@ __global__ __launch_bounds__(OWNK == 2 ? NTHR / 2 : NTHR, UFM_RELAX_WAVES) void 
                         break;
                     }
                 }
+                if constexpr (NWV == 8) UFM_SETPRIO(UFM_VISIT_PRIO);
                 if (!vote) continue;
             } else if (bits && lane == 0) {
                 __hip_atomic_fetch_or(&s_wake[wp], bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // put back what was taken
