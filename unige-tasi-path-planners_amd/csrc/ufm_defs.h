@@ -73,7 +73,8 @@ constexpr int NTHR = 1024;     // 16 waves; four lanes per node, each wave owns 
 #define UFM_STEAL_VICTIMS 4    // owners whose words an idle workgroup looks at per look (k_relax, own_steal)
 #endif
 #ifndef UFM_EARLY_POLLS
-#define UFM_EARLY_POLLS 6      // ... its queue words follow after this many looks of the idle wave at its wake bits (the stores have landed by then)
+#define UFM_EARLY_POLLS 2      // ... its queue words follow after this many looks of the idle wave at its wake bits (round 4, looks 128 clocks apart: 1 / 2 / 6 / 10 / 16
+                               // looks -> SG 2048^2 plan kernel 5.00 / 5.00 / 5.15 / 5.21 / 5.32 ms; the wave waits for its stores first in any case)
 #endif
 // Issue priority (s_setprio): waves that sweep, stage or write back run above waves that only look -- an idle wave of a visit at its wake bits,
 // a workgroup without a tile at the queue words -- so that on a SIMD the looks do not take issue slots from the wave on the chain.  In the 8-wave form
@@ -88,8 +89,8 @@ constexpr int NTHR = 1024;     // 16 waves; four lanes per node, each wave owns 
 #define UFM_SETPRIO(x) do {} while (0)
 #endif
 #ifndef UFM_IDLE_SLEEP
-#define UFM_IDLE_SLEEP 4
-#endif
+#define UFM_IDLE_SLEEP 2      // an idle wave of a tile visit looks at its wake bits this often (x 64 clocks).  Round 4, with the issue priorities in place: 1 / 2 / 4 / 8 ->
+#endif                       // FD 4096^2 plan kernel 13.62 / 13.53 / 13.63 / 13.8 ms, SG 2048^2 (16 waves, in-visit refresh) 5.07 / 5.10 / 5.25 / 5.46 ms
 #ifndef UFM_DIRWAKE
 #define UFM_DIRWAKE 0          // resident kernel: a re-visit wakes the patches along the halo entries that changed since the tile's last visit, not all sixteen
 #endif                         // (round 4, measured, diagnostic builds only: FD 4096^2 evaluations per element 29.3 -> 27.4, plan kernel 14.10 -> 14.50 ms; 8192^2 24.3 -> 22.9,
