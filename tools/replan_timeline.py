@@ -25,4 +25,5 @@ for i, (k, s, top, left, patch) in enumerate(script):
     print("replan %2d %4.0f us | B %.0f B0 %.0f rbound %.0f done %d exp %d | deferrals L %d R %d again l %d r %d | bursts raise %d lower %d sweeps raise %d lower %d" % (
         k, dt, f[0], f[1], f[2], dbg[9], dbg[12], dbg[22], dbg[23], dbg[24], dbg[25], dbg[26], dbg[27], dbg[28], dbg[29]), "| us: begin %.1f stage %.1f raise %.1f lower %.1f writeback %.1f check %.1f" % tuple(0.01 * (dbg[31 + i] - (dbg[30 + i] if i else 0)) for i in range(6)),
           "| prologue at us: patch asked %.1f, all asked %.1f, staged %.1f, patch applied %.1f, seeded %.1f, bookkeeping %.1f, seeds read %.1f" % tuple(0.01 * dbg[41 + i] for i in (0, 6, 1, 2, 3, 4, 5)),
+          "| bursts that changed nothing: lower %d (all +inf around: %d), raise %d" % (dbg[70], dbg[71], dbg[72]),
           "| SIMD of waves 0..15:", "".join(str(int(v)) for v in dbg[50:66]))

@@ -101,6 +101,7 @@ struct RegionShared {
     int m_r, m_l, done;
     int dkey;                             // smallest KEY (value + hm * dist) lowering held back in the current sub-round (float bits)
     int dbg[8];                           // diagnostics
+    int dbg2[8];                          // diagnostics: [0] lowering bursts that changed nothing, [1] ... whose patch and its 1-element surround held nothing but +inf, [2] invalidation bursts that changed nothing
     unsigned long long tstamp[12];        // diagnostics: wall_clock64 at the phase boundaries
 };
 
@@ -183,6 +184,8 @@ __device__ void region_phase(const DevParams &P, const RegionJob &J, float *Gs, 
             if (lane == 0) bits = atomicExch(&S.wake[w][wd], 0);
             bits = __builtin_amdgcn_readfirstlane(bits);
             if (!bits) continue;
+            // (Round 4: re-lowering only the patches that LOST a value, and the seeded ones, starts the lowering phase with a quarter fewer patches and
+            //  ends with as many bursts -- the neighbours' wake bits bring the others in anyway: 16.4 ms per 100 replans either way.)
             if (MODE == MODE_RAISE && lane == 0) S.ever[w][wd] |= bits;      // only this wave writes its own words
             // Invalidation of the node planners follows the stored back-pointers: an element is gone when a vertex its value depends on is gone
             // (the byte's dep bits: two LDS loads and a compare, no operator, no per-patch constants).  Only where cell costs changed -- the
@@ -245,6 +248,11 @@ __device__ void region_phase(const DevParams &P, const RegionJob &J, float *Gs, 
                 const float rb = (MODE == MODE_RAISE && S.traised[tl]) ? INFINITY : rb_phase;
                 asm volatile("" ::: "memory");
                 float g = ctr[0];
+                if (dbg_count && MODE == MODE_LOWER) {
+                    const int sx_ = (q & 2) ? RP : -RP, sy_ = (q & 1) ? 1 : -1;
+                    const bool fin = (g < INFINITY) | (ctr[sx_] < INFINITY) | (ctr[sy_] < INFINITY) | (ctr[sx_ + sy_] < INFINITY);
+                    if (__builtin_amdgcn_ballot_w64(fin) == 0ull && lane == 0) atomicAdd(&S.dbg2[1], 1);
+                }
                 float dmin = INFINITY;                                        // smallest priority this lane deferred
                 float rmin_l = INFINITY;                                      // smallest value this lane invalidated
                 bool again = true, pch = false;
@@ -295,7 +303,7 @@ __device__ void region_phase(const DevParams &P, const RegionJob &J, float *Gs, 
                     if (lane == 0 && held == 0ull) S.seed[w][wd] &= ~(1 << j);
                 }
                 if (MODE == MODE_RAISE && rmin_l < INFINITY && q == 0) { atomicMin(&S.rmin, __float_as_int(rmin_l)); S.traised[tl] = 1; }
-                if (dbg_count && lane == 0) { atomicAdd(&S.dbg[MODE == MODE_LOWER ? 5 : 4], 1); atomicAdd(&S.dbg[MODE == MODE_LOWER ? 7 : 6], cnt); }
+                if (dbg_count && lane == 0) { atomicAdd(&S.dbg[MODE == MODE_LOWER ? 5 : 4], 1); atomicAdd(&S.dbg[MODE == MODE_LOWER ? 7 : 6], cnt); if (!pch) atomicAdd(&S.dbg2[MODE == MODE_LOWER ? 0 : 2], 1); }
                 if (again && lane == 0) __hip_atomic_fetch_or(&S.wake[w][wd], 1 << j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // burst cap
                 if (dmin < INFINITY && q == 0) {
                     atomicAdd(&S.dbg[MODE == MODE_LOWER ? 0 : 1], 1);
@@ -868,6 +876,7 @@ __global__ __launch_bounds__(NTHR) void k_replan_region(DevParams P, RegionJobs 
                 for (int i = 1; i < 7; ++i) d[30 + i] = (int)(S.tstamp[i] - S.tstamp[0]);
                 for (int i = 1; i < 8; ++i) d[40 + i] = (int)(s_tb[i] - s_tb[0]);
                 for (int i = 0; i < 16; ++i) d[50 + i] = s_simd[i];
+                for (int i = 0; i < 8; ++i) d[70 + i] = S.dbg2[i];
             }
         }
         __syncthreads();
