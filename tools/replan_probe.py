@@ -32,6 +32,7 @@ for rep in range(3):
         times.append(time.perf_counter() - t); cells += p.stats.expanded; visits += p.stats.tile_visits; evals += p.stats.elem_evals
         if times[-1] > 1e-3: print("   slow replan %d: %.0f us, launches %d (raise %d), region done %d/%d, expanded %d, visits %d, u_ms %.2f p_ms %.2f" % (i, times[-1] * 1e6, p.stats.launches, p.stats.raise_launches, p.stats.region_replans_done, p.stats.region_replans, p.stats.expanded, p.stats.tile_visits, p.stats.u_ms, p.stats.p_ms), flush=True)
     ts = np.array(times) * 1e6
+    if rep == 2: print("   slowest:", ", ".join("#%d %.0f us" % (i, ts[i]) for i in np.argsort(-ts)[:10]), "| sum without them %.2f ms" % (np.sort(ts)[:-10].sum() / 1e3), flush=True)
     print("%s %d^2 %s: plan %.2f ms; 100 replans %.2f ms (median %.0f us, p90 %.0f, max %.0f); block kernel %d/%d done; cells %d visits %d patch-sweeps/replan %d launches(last) %d back-pointers %s" % (
         algo, size, params, t_plan * 1e3, ts.sum() / 1e3, np.median(ts), np.percentile(ts, 90), ts.max(),
         p.stats.region_replans_done, p.stats.region_replans, cells, visits, evals // 1600, p.stats.launches, p.check_info() if algo != "DFM" else "-"), flush=True)
