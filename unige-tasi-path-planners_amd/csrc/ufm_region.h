@@ -256,6 +256,7 @@ __device__ void region_phase(const DevParams &P, const RegionJob &J, float *Gs, 
                 float dmin = INFINITY;                                        // smallest priority this lane deferred
                 float rmin_l = INFINITY;                                      // smallest value this lane invalidated
                 bool again = true, pch = false;
+                unsigned long long chg = 0ull;                              // lanes whose node the burst changed
                 int cnt = 0;
                 for (int b = 0; b < 16 && again; ++b) {
                     asm volatile("" ::: "memory");                          // re-read the block every sweep (other waves write it)
@@ -287,6 +288,7 @@ __device__ void region_phase(const DevParams &P, const RegionJob &J, float *Gs, 
                     const unsigned long long wanted = __builtin_amdgcn_ballot_w64(want & gate);   // lanes not yet settled (a colour-gated rise waits for its sweep)
                     g = gn;
                     pch |= mask != 0ull;
+                    chg |= mask;
                     UFM_SWEEP_FENCE();                                        // value before wake bit
                     if (mask != 0ull && lane == 0) S.tflag[tl] = 1;             // the tile holds changed values (write-back looks at these tiles only)
                     if ((mask & wake_sel) != 0ull && nword >= 0 && lane != 4)
@@ -296,7 +298,9 @@ __device__ void region_phase(const DevParams &P, const RegionJob &J, float *Gs, 
                 }
                 budget -= cnt; my_sweeps += cnt;
                 // (the patch and the eight around it: lanes 0..8 hold their wake words anyway)
-                if (pch && nword >= 0) __hip_atomic_fetch_or(&S.renew[nwave][nword], nbit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                // (... of the patches around it only those that border a node the burst changed -- the wake-up's own test: a node none of whose eight
+                //  neighbours has changed keeps its parent triangle.  Round 4; before, all eight: a third more patches to renew.)
+                if ((chg & wake_sel) != 0ull && nword >= 0) __hip_atomic_fetch_or(&S.renew[nwave][nword], nbit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 // (a seeded patch that had to hold a result back is evaluated once more when it is woken again)
                 if (BPRAISE && arith) {
                     const unsigned long long held = __builtin_amdgcn_ballot_w64(dmin < INFINITY);
