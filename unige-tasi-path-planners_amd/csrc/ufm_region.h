@@ -157,6 +157,12 @@ __device__ void region_phase(const DevParams &P, const RegionJob &J, float *Gs, 
         if (dc < 0) wake_sel &= 0x000F000F000F000Full; else if (dc > 0) wake_sel &= 0xF000F000F000F000ull;
     }
     const int colour = ((nd >> 2) & 1) | ((nd & 1) << 1);
+    // a patch's 3 x 3 neighbours: patch (pr, pc) belongs to wave ((pr & 3) << 2) | (pc & 3) and is bit (pr >> 2) * RPW + (pc >> 2) of that wave's words; this
+    // wave's patches all have (pr & 3, pc & 3) = (w >> 2, w & 3), so the neighbour's wave and the distance of its bit from this patch's bit are per-lane constants
+    const bool wt_lane = lane < 9;
+    const int wt_dr = wt_lane ? lane / 3 - 1 : 0, wt_dc = wt_lane ? lane % 3 - 1 : 0;
+    const int wt_ar = (w >> 2) + wt_dr, wt_ac = (w & 3) + wt_dc;                       // -1 .. 4
+    const int wt_wave = ((wt_ar & 3) << 2) | (wt_ac & 3), wt_di = (wt_ar >> 2) * RPW + (wt_ac >> 2);
     const float sx = J.rb.sb.sx, sy = J.rb.sb.sy;
     const int rx0 = J.tx0 * T, ry0 = J.ty0 * T;
     long long budget = J.max_sweeps;
@@ -219,16 +225,11 @@ __device__ void region_phase(const DevParams &P, const RegionJob &J, float *Gs, 
                 const int bo1 = (bpb & 4) ? bsy : bsx, bo2 = bsx + bsy;
                 const bool bd1 = bpb & 1, bd2 = bpb & 2;
                 const bool goal = (lx == goal_lx) & (ly == goal_ly);
-                // wake targets: lane 0..8 = the 3x3 patches around this one (lane 4: itself)
-                int nwave = 0, nword = -1, nbit = 0;
-                if (lane < 9) {
-                    const int npr = pr + lane / 3 - 1, npc = pc + lane % 3 - 1;
-                    if (npr >= 0 && npr < nprow && npc >= 0 && npc < npcol) {
-                        nwave = ((npr & 3) << 2) | (npc & 3);
-                        const int ni = (npr >> 2) * RPW + (npc >> 2);
-                        nword = ni >> 5; nbit = 1 << (ni & 31);
-                    }
-                }
+                // wake targets: lane 0..8 = the 3x3 patches around this one (lane 4: itself).  Which wave a neighbouring patch belongs to and how far its
+                // bit lies from this patch's own do not depend on the patch (wt_*, above the loop): per burst only the position and the range test are left
+                const int npr = pr + wt_dr, npc = pc + wt_dc, ni = idx + wt_di;
+                const bool wt_ok = wt_lane & ((unsigned)npr < (unsigned)nprow) & ((unsigned)npc < (unsigned)npcol);
+                const int nwave = wt_wave, nword = wt_ok ? (ni >> 5) : -1, nbit = 1 << (ni & 31);
                 // admissible part of the key that does not depend on the value: hm * dist(start, patch)
                 float hd = 0.0f;
                 if (hm != 0.0f) {
