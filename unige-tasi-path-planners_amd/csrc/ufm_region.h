@@ -165,8 +165,8 @@ __device__ void region_phase(const DevParams &P, const RegionJob &J, float *Gs, 
     const int wt_wave = ((wt_ar & 3) << 2) | (wt_ac & 3), wt_di = (wt_ar >> 2) * RPW + (wt_ac >> 2);
     const float sx = J.rb.sb.sx, sy = J.rb.sb.sy;
     const int rx0 = J.tx0 * T, ry0 = J.ty0 * T;
-    long long budget = J.max_sweeps;
-    unsigned long long my_sweeps = 0;
+    int budget = J.max_sweeps;               // (per wave and phase)
+    unsigned int my_sweeps = 0;
     auto cost_at = [=](int r, int c) { const int b = Cb[r * RCP + c]; return b >= thr ? INFINITY : (float)b; };
     // what does not change while a phase runs (thread 0 sets it between the phases): read once, not at every burst
     const int so0 = __builtin_amdgcn_readfirstlane(S.soff[0]), so1 = __builtin_amdgcn_readfirstlane(S.soff[1]);
@@ -348,7 +348,7 @@ __device__ void region_phase(const DevParams &P, const RegionJob &J, float *Gs, 
         __syncthreads();
     }
     UFM_REGION_SETPRIO(0);
-    if (lane == 0 && my_sweeps) atomicAdd(&S.sweeps, my_sweeps);
+    if (lane == 0 && my_sweeps) atomicAdd(&S.sweeps, (unsigned long long)my_sweeps);
     __syncthreads();
     if (tid == 0) S.idle = 0;
     __syncthreads();
