@@ -257,6 +257,9 @@ __device__ void region_phase(const DevParams &P, const RegionJob &J, float *Gs, 
                 float dmin = INFINITY;                                        // smallest priority this lane deferred
                 float rmin_l = INFINITY;                                      // smallest value this lane invalidated
                 bool again = true, pch = false;
+                [[maybe_unused]] bool held_last = false;
+                [[maybe_unused]] float nv_last = INFINITY;
+                [[maybe_unused]] const bool gate_free = is_start || B == INFINITY || dbg_nogate;      // lowering: a start element itself is never held back
                 unsigned long long chg = 0ull;                              // lanes whose node the burst changed
                 int cnt = 0;
                 for (int b = 0; b < 16 && again; ++b) {
@@ -270,10 +273,12 @@ __device__ void region_phase(const DevParams &P, const RegionJob &J, float *Gs, 
                     if (goal) nv = 0.0f;
                     bool want, gate, doit;
                     if (MODE == MODE_LOWER) {
+                        // (lane conditions as `&&` / `||` of comparisons: written with `&` / `|` next to the wave-uniform flags they were materialised as
+                        //  0 / 1 integers and combined by vector instructions, a dozen per sweep)
                         want = (nv != g);
-                        gate = (nv + hd < B) | (B == INFINITY) | is_start | dbg_nogate;    // end_condition: results at / beyond the start's key wait
-                        doit = want & gate & ((nv < g) | (colour == (cnt & 3)));
-                        if (want & !gate) dmin = fminf(dmin, nv);
+                        gate = (nv + hd < B) || gate_free;                     // end_condition: results at / beyond the start's key wait
+                        doit = want && gate && ((nv < g) || (colour == (cnt & 3)));
+                        held_last = want && !gate; nv_last = nv;              // (what the LAST sweep holds back is what the burst leaves pending: dmin below)
                     } else {
                         if (is_dfm<ALGO>) want = (g < INFINITY) & (nv > g) & ((nv == INFINITY) | (__float_as_int(nv) - __float_as_int(g) > 8));
                         else want = (g < INFINITY) & (nv > g);
@@ -285,8 +290,8 @@ __device__ void region_phase(const DevParams &P, const RegionJob &J, float *Gs, 
                     }
                     if (doit && q == 0) ctr[0] = nv;
                     const float gn = doit ? nv : g;
-                    const unsigned long long mask = __builtin_amdgcn_ballot_w64(gn != g);
-                    const unsigned long long wanted = __builtin_amdgcn_ballot_w64(want & gate);   // lanes not yet settled (a colour-gated rise waits for its sweep)
+                    const unsigned long long mask = __builtin_amdgcn_ballot_w64(doit);            // (= gn != g: what is applied differs from g in either mode)
+                    const unsigned long long wanted = __builtin_amdgcn_ballot_w64(want && gate);  // lanes not yet settled (a colour-gated rise waits for its sweep)
                     g = gn;
                     pch |= mask != 0ull;
                     chg |= mask;
@@ -298,6 +303,7 @@ __device__ void region_phase(const DevParams &P, const RegionJob &J, float *Gs, 
                     again = wanted != 0ull;
                 }
                 budget -= cnt; my_sweeps += cnt;
+                if (MODE == MODE_LOWER && held_last) dmin = nv_last;
                 // (the patch and the eight around it: lanes 0..8 hold their wake words anyway)
                 // (... of the patches around it only those that border a node the burst changed -- the wake-up's own test: a node none of whose eight
                 //  neighbours has changed keeps its parent triangle.  Round 4; before, all eight: a third more patches to renew.)
