@@ -267,7 +267,7 @@ __device__ void region_phase(const DevParams &P, const RegionJob &J, float *Gs, 
                     float nv;
                     if constexpr (BPRAISE) {
                         if (arith && b == 0) nv = quad_min(eval_quad_bp<ALGO, RP>(ctr, q, C, bpb));
-                        else nv = ((bd1 & (ctr[bo1] == INFINITY)) | (bd2 & (ctr[bo2] == INFINITY))) ? INFINITY : g;
+                        else { const float p1 = ctr[bo1], p2 = ctr[bo2]; nv = ((bd1 && p1 == INFINITY) || (bd2 && p2 == INFINITY)) ? INFINITY : g; }   // (both loads asked for at once)
                     }
                     else nv = quad_min(eval_quad<ALGO, RP>(ctr, q, C));
                     if (goal) nv = 0.0f;
@@ -280,11 +280,11 @@ __device__ void region_phase(const DevParams &P, const RegionJob &J, float *Gs, 
                         doit = want && gate && ((nv < g) || (colour == (cnt & 3)));
                         held_last = want && !gate; nv_last = nv;              // (what the LAST sweep holds back is what the burst leaves pending: dmin below)
                     } else {
-                        if (is_dfm<ALGO>) want = (g < INFINITY) & (nv > g) & ((nv == INFINITY) | (__float_as_int(nv) - __float_as_int(g) > 8));
-                        else want = (g < INFINITY) & (nv > g);
-                        gate = !(g > rb) | dbg_nogate;                                               // beyond the invalidation bound: wait
-                        doit = want & gate;
-                        if (want & !gate) dmin = fminf(dmin, g);
+                        if (is_dfm<ALGO>) want = (g < INFINITY) && (nv > g) && ((nv == INFINITY) || (__float_as_int(nv) - __float_as_int(g) > 8));
+                        else want = (g < INFINITY) && (nv > g);
+                        gate = !(g > rb) || dbg_nogate;                                              // beyond the invalidation bound: wait
+                        doit = want && gate;
+                        if (want && !gate) dmin = fminf(dmin, g);
                         rmin_l = doit ? fminf(rmin_l, g) : rmin_l;        // (what the burst took away: into S.rmin / S.traised after it, not per sweep)
                         nv = INFINITY;
                     }
