@@ -65,6 +65,17 @@ struct TriFD {
         bI = (c > b * SQRT2F) ? b : INFINITY;
         if (c == INFINITY) { bp = INFINITY; cbp = -1.0f; }
     }
+    // both triangles of a lane at once (k_replan_region sets these up at every burst): the two square roots side by side and unconditionally -- as two
+    // `cgb ? sqrt_rn(..) : -1` they became two exec-mask branches one after the other, each a dozen dependent instructions long
+    static __device__ __forceinline__ void set2(TriFD &tv, TriFD &th, float c, float bv, float bh) {
+        const float c2 = c * c;
+        float sv = sqrt_rn(fmaxf(c2 - bv * bv, 0.0f)), sh = sqrt_rn(fmaxf(c2 - bh * bh, 0.0f));
+        asm volatile("" : "+v"(sv), "+v"(sh));
+        const bool gv = c > bv, gh = c > bh, cinf = c == INFINITY;
+        tv.bp = cinf ? INFINITY : (gv ? bv : c); th.bp = cinf ? INFINITY : (gh ? bh : c);
+        tv.cbp = (gv && !cinf) ? sv : -1.0f; th.cbp = (gh && !cinf) ? sh : -1.0f;
+        tv.bI = (c > bv * SQRT2F) ? bv : INFINITY; th.bI = (c > bh * SQRT2F) ? bh : INFINITY;
+    }
 };
 __device__ __forceinline__ float tri_fd(float g1, float g2, const CellFD &K, const TriFD &Q) {
     const float f = g1 - g2;
@@ -122,8 +133,7 @@ template <> struct QuadConsts<UFM_ALGO_FD> {
         const float bv = cost(lx + dx, ly + 1 - dy);   // across the vertical edge s-p1
         const float bh = cost(lx + 1 - dx, ly + dy);   // across the horizontal edge s-p1
         k = {c, c * c, c * SQRT2F};
-        tv.set(c, bv);
-        th.set(c, bh);
+        TriFD::set2(tv, th, c, bv, bh);
     }
     __device__ __forceinline__ void load(const float *Cs, int lx, int ly, int q) { load_at([=](int r, int c) { return Cs[r * CP + c]; }, lx, ly, q, GP); }
 };
