@@ -296,13 +296,13 @@ __device__ void region_phase(const DevParams &P, const RegionJob &J, float *Gs, 
                     pch |= mask != 0ull;
                     chg |= mask;
                     UFM_SWEEP_FENCE();                                        // value before wake bit
-                    if (mask != 0ull && lane == 0) S.tflag[tl] = 1;             // the tile holds changed values (write-back looks at these tiles only)
                     if ((mask & wake_sel) != 0ull && nword >= 0 && lane != 4)
                         __hip_atomic_fetch_or(&S.wake[nwave][nword], nbit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                     ++cnt;
                     again = wanted != 0ull;
                 }
                 budget -= cnt; my_sweeps += cnt;
+                if (pch && lane == 0) S.tflag[tl] = 1;                      // the tile holds changed values (write-back looks at these tiles only)
                 if (MODE == MODE_LOWER && held_last) dmin = nv_last;
                 // (the patch and the eight around it: lanes 0..8 hold their wake words anyway)
                 // (... of the patches around it only those that border a node the burst changed -- the wake-up's own test: a node none of whose eight
@@ -405,6 +405,7 @@ __global__ __launch_bounds__(NTHR) void k_replan_region(DevParams P, RegionJobs 
         if (e >= 0) { const int x = e / P.EY; sg = P.G[gaddr(P, m, x, e - x * P.EY)]; }
     }
     const int n_pending = P.ctr->scount;
+    const int goal_x = P.goal[2 * m], goal_y = P.goal[2 * m + 1];      // (asked for here: read where it is used, in front of the phases, it was a memory round trip of its own)
     // ---- 0a. stage the block: the cost bytes (a patch that comes with the job is applied on top of them), the tiles (contiguous 1 KB each)
     // with their back-pointer bytes, the 1-element frame around the block ----
     // (Work is dealt out by wave -- a row piece of 64 cost bytes, a quarter KB of a tile -- so that which row / which tile is the wave's scalar
@@ -587,7 +588,7 @@ __global__ __launch_bounds__(NTHR) void k_replan_region(DevParams P, RegionJobs 
     }
     if (tid < 4) S.swas[tid] = (S.soff[tid] >= 0 && Gs[S.soff[tid]] < INFINITY) ? 1 : 0;
     __syncthreads();
-    const int goal_lx = P.goal[2 * m] - rx0, goal_ly = P.goal[2 * m + 1] - ry0;
+    const int goal_lx = goal_x - rx0, goal_ly = goal_y - ry0;
 
     // ---- 2. invalidate, lower; again while an invalidation that was held back lies below the start's new key ----
     for (int round = 0;; ++round) {
