@@ -370,7 +370,6 @@ __global__ __launch_bounds__(NTHR) void k_replan_region(DevParams P, RegionJobs 
     __shared__ uint8_t s_pmask[4096];     // change mask of a patch that comes with the job (<= 64 x 64 cells)
     __shared__ int s_simd[16];               // diagnostics: the SIMD each wave runs on
     __shared__ unsigned long long s_tb[8];   // diagnostics: the prologue's timeline
-    __shared__ float s_sg[4];             // the start elements' values before the step
     constexpr bool CELLS = is_dfm<ALGO>;
     constexpr int COFF = CELLS ? 0 : 1;
     const int tid = threadIdx.x;
@@ -400,9 +399,10 @@ __global__ __launch_bounds__(NTHR) void k_replan_region(DevParams P, RegionJobs 
         for (int c = 0; c < 4; ++c) { const int e = tid + c * NTHR; if (e < n0) pb0[c] = J.psrc[r_first][e]; }
     }
     float sg = INFINITY;
+    int se_x = -1, se_y = -1;             // threads 0..3: this thread's start element (-1: none)
     {   // (not J.rb.sb.start[tid]: indexing the kernel's arguments by thread is a memory load, waited for with the host's bytes in front of it)
         const int e = tid == 0 ? J.rb.sb.start[0] : (tid == 1 ? J.rb.sb.start[1] : (tid == 2 ? J.rb.sb.start[2] : (tid == 3 ? J.rb.sb.start[3] : -1)));
-        if (e >= 0) { const int x = e / P.EY; sg = P.G[gaddr(P, m, x, e - x * P.EY)]; }
+        if (e >= 0) { se_x = e / P.EY; se_y = e - se_x * P.EY; sg = P.G[gaddr(P, m, se_x, se_y)]; }
     }
     const int n_pending = P.ctr->scount;
     const int goal_x = P.goal[2 * m], goal_y = P.goal[2 * m + 1];      // (asked for here: read where it is used, in front of the phases, it was a memory round trip of its own)
@@ -476,7 +476,6 @@ __global__ __launch_bounds__(NTHR) void k_replan_region(DevParams P, RegionJobs 
         }
         if (fo >= 0) Gs[fo] = fv;
     }
-    if (tid < 4) s_sg[tid] = sg;
     // ---- 0b. Graph::update (Graph.cpp:36-51) + the seeding of update() for the patches that come with the job -- what k_patch_small does for a
     // patch applied at the call.  Every rectangle lies inside the block (place_job), so the old bytes are in Cb: compare there, write the changed
     // ones to the raster, to the cost windows and to Cb; the change mask stays in LDS.  In the order the patches were handed over (they may overlap).
@@ -548,24 +547,27 @@ __global__ __launch_bounds__(NTHR) void k_replan_region(DevParams P, RegionJobs 
         }
         __syncthreads();
         STAMP(6);
-        if (tid == 0) {
-            if (!J.batch) { P.ctr->scount = 0; P.ctr->done = 0; }   // (a batch: the last workgroup, when everybody has read the list)
-            // the start's key before the patch (start_bound(), from the values asked for at the top)
-            float b0 = 0.0f;
-            bool in = false;
-            for (int i = 0; i < 4; ++i) {
-                const int e = J.rb.sb.start[i];
-                S.soff[i] = -1; S.sdist[i] = 0.0f;
-                if (e < 0) continue;
-                const int x = e / P.EY, y = e - x * P.EY;
-                S.sdist[i] = hm * hypotf(J.rb.sb.sx - (float)x, J.rb.sb.sy - (float)y);
-                if (s_sg[i] < INFINITY) b0 = fmaxf(b0, s_sg[i] + S.sdist[i]);
-                if (x >= rx0 && x < rx0 + rnx && y >= ry0 && y < ry0 + rny) { S.soff[i] = (x - rx0 + 1) * RP + (y - ry0 + 1); in = true; }
+        if (tid == 0 && !J.batch) { P.ctr->scount = 0; P.ctr->done = 0; }   // (a batch: the last workgroup, when everybody has read the list)
+        if (tid < 64) {
+            // the start's key before the patch (start_bound(), from the values asked for at the top): one start element per lane 0..3 (one thread
+            // after the other -- four divisions, four hypotf -- this was a microsecond in front of the phases), the largest key by two shuffles
+            float key = 0.0f, dist = 0.0f;
+            int off = -1;
+            if (se_x >= 0) {
+                dist = hm * hypotf(J.rb.sb.sx - (float)se_x, J.rb.sb.sy - (float)se_y);
+                if (sg < INFINITY) key = sg + dist;
+                if (se_x >= rx0 && se_x < rx0 + rnx && se_y >= ry0 && se_y < ry0 + rny) off = (se_x - rx0 + 1) * RP + (se_y - ry0 + 1);
             }
-            b0 = b0 > 0.0f ? b0 : INFINITY;
-            S.B0 = b0;
-            S.rbound = focused ? b0 + J.rb.band : INFINITY;
-            S.any_start_in = in ? 1 : 0;
+            if (tid < 4) { S.soff[tid] = off; S.sdist[tid] = dist; }
+            const bool in = __builtin_amdgcn_ballot_w64(off >= 0) != 0ull;
+            float b0 = fmaxf(key, __shfl_xor(key, 1));
+            b0 = fmaxf(b0, __shfl_xor(b0, 2));
+            if (tid == 0) {
+                b0 = b0 > 0.0f ? b0 : INFINITY;
+                S.B0 = b0;
+                S.rbound = focused ? b0 + J.rb.band : INFINITY;
+                S.any_start_in = in ? 1 : 0;
+            }
         }
     }
 
