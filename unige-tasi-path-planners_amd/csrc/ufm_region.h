@@ -376,6 +376,9 @@ __global__ __launch_bounds__(NTHR) void k_replan_region(DevParams P, RegionJobs 
     const RegionJob &J = JS.j[blockIdx.x];
     const int m = J.map, gt0 = m * P.NTm;                     // the job's map and its first tile
     const int ntl = J.ntx * J.nty;
+    // tile index of the block -> its row: tl / nty as a multiplication (exact for tl < 256, nty <= 8): the staging and write-back loops divided once per
+    // iteration and thread, ~25 instructions each
+    const int nty_magic = (65536 + J.nty - 1) / J.nty;
     const int rx0 = J.tx0 * T, ry0 = J.ty0 * T, rnx = J.ntx * T, rny = J.nty * T;
 
     const unsigned long long t_begin = wall_clock64();
@@ -436,7 +439,7 @@ __global__ __launch_bounds__(NTHR) void k_replan_region(DevParams P, RegionJobs 
         for (int k = 0; k < KT; ++k) {
             const int pc = wv + 16 * k, tl = pc / CPT;
             if (tl >= ntl) continue;
-            const int ti = tl / J.nty, tj = tl - ti * J.nty, v = (pc - tl * CPT) * 64 + ln;
+            const int ti = (tl * nty_magic) >> 16, tj = tl - ti * J.nty, v = (pc - tl * CPT) * 64 + ln;
             const size_t gt = (size_t)(gt0 + (J.tx0 + ti) * P.TY + J.ty0 + tj);
             gv[k] = reinterpret_cast<const float4 *>(P.G + gt * TT)[v];
             bv[k] = reinterpret_cast<const unsigned int *>(P.bp + gt * TT)[v];
@@ -469,7 +472,7 @@ __global__ __launch_bounds__(NTHR) void k_replan_region(DevParams P, RegionJobs 
         for (int k = 0; k < KT; ++k) {
             const int pc = wv + 16 * k, tl = pc / CPT;
             if (tl >= ntl) continue;
-            const int ti = tl / J.nty, tj = tl - ti * J.nty, e = ((pc - tl * CPT) * 64 + ln) * 4;
+            const int ti = (tl * nty_magic) >> 16, tj = tl - ti * J.nty, e = ((pc - tl * CPT) * 64 + ln) * 4;
             float *g = &Gs[(ti * T + e / T + 1) * RP + tj * T + e % T + 1];
             g[0] = gv[k].x; g[1] = gv[k].y; g[2] = gv[k].z; g[3] = gv[k].w;
             *reinterpret_cast<unsigned int *>(&Bb[(ti * T + e / T) * RBP + tj * T + e % T]) = bv[k];
@@ -711,7 +714,7 @@ __global__ __launch_bounds__(NTHR) void k_replan_region(DevParams P, RegionJobs 
         const int i = tid + it * NTHR, tl = __builtin_amdgcn_readfirstlane(i / TT);
         init[it] = 0.0f;
         if (tl >= ntl) continue;
-        const int e = i - tl * TT, ti = tl / J.nty, tj = tl - ti * J.nty;
+        const int e = i - tl * TT, ti = (tl * nty_magic) >> 16, tj = tl - ti * J.nty;
         const size_t gt = (size_t)(gt0 + (J.tx0 + ti) * P.TY + J.ty0 + tj);
         // the renewed back-pointers of the tile (a patch next to a changed one may lie in an unchanged tile)
         if (S.tbp[tl]) P.bp[gt * TT + e] = Bb[(ti * T + e / T) * RBP + tj * T + e % T];
@@ -721,7 +724,7 @@ __global__ __launch_bounds__(NTHR) void k_replan_region(DevParams P, RegionJobs 
     for (int it = 0; it < PER; ++it) {
         const int i = tid + it * NTHR, tl = __builtin_amdgcn_readfirstlane(i / TT);
         if (tl >= ntl) continue;
-        const int e = i - tl * TT, ti = tl / J.nty, tj = tl - ti * J.nty;
+        const int e = i - tl * TT, ti = (tl * nty_magic) >> 16, tj = tl - ti * J.nty;
         if (!S.tflag[tl]) continue;                                         // nothing was applied in this tile
         const int tx = J.tx0 + ti, ty = J.ty0 + tj, gt = gt0 + tx * P.TY + ty;
         const int io_r = e / T, io_c = e % T;
