@@ -486,13 +486,14 @@ __global__ __launch_bounds__(NTHR) void k_replan_region(DevParams P, RegionJobs 
         if (!J.psrc[r]) continue;
         const int *qr = J.rb.rect[r];                       // {map, x, y, w, h}
         const int px = qr[1], py = qr[2], pw = qr[3], ph = qr[4];
+        const unsigned pw_magic = ((1u << 20) + (unsigned)pw - 1u) / (unsigned)pw;      // (patches are at most 64 x 64 cells: host side)
         __syncthreads();                                    // Cb staged / the previous rectangle's seeds read
         STAMP(2);
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
             const int e = tid + c * NTHR;
             if (e >= pw * ph) continue;
-            const int i = e / pw, j = e - i * pw;
+            const int i = (int)(((unsigned)e * pw_magic) >> 20), j = e - i * pw;      // (e / pw: exact for e < 4400, pw <= 65)
             uint8_t *cb = &Cb[(px + i - rx0 + COFF) * RCP + (py + j - ry0 + COFF)];
             const uint8_t nv = (r == r_first) ? (uint8_t)pb0[c] : J.psrc[r][e];
             const uint8_t ch = *cb != nv;
@@ -507,9 +508,10 @@ __global__ __launch_bounds__(NTHR) void k_replan_region(DevParams P, RegionJobs 
             // have been counted already (the marks, which are for that, are all clear between steps and stay clear), and every seeded tile lies
             // inside the block (no seed list).  Counted per wave, one atomic each.
             const int ew = CELLS ? pw : pw + 1;
+            const unsigned ew_magic = ((1u << 20) + (unsigned)ew - 1u) / (unsigned)ew;
             int cnt = 0;
             for (int e = tid; e < ne; e += NTHR) {
-                const int i = e / ew, j = e - i * ew;
+                const int i = (int)(((unsigned)e * ew_magic) >> 20), j = e - i * ew;
                 bool ch;
                 if (!CELLS) ch = (i > 0 && j > 0 && s_pmask[(i - 1) * pw + j - 1]) || (i > 0 && j < pw && s_pmask[(i - 1) * pw + j]) ||
                                  (i < ph && j > 0 && s_pmask[i * pw + j - 1]) || (i < ph && j < pw && s_pmask[i * pw + j]);
