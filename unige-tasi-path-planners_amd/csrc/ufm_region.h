@@ -367,6 +367,10 @@ __global__ __launch_bounds__(NTHR) void k_replan_region(DevParams P, RegionJobs 
     __shared__ __attribute__((aligned(16))) uint8_t Bb[RN * RBP];
     __shared__ RegionShared S;
     __shared__ int s_last;
+    constexpr int NG0 = (46 * 1024) / (TT * 4);      // tiles of the write-back's LDS copy of what HBM holds: what the CU's 160 KB leave (46 KB; a 6 x 6 block needs 36)
+    __shared__ float G0c[NG0 * TT];
+    __shared__ int s_wbl[RTMAX * RTMAX];  // write-back: the tiles that have something to write
+    __shared__ int s_nwb;
     __shared__ uint8_t s_pmask[4096];     // change mask of a patch that comes with the job (<= 64 x 64 cells)
     __shared__ int s_simd[16];               // diagnostics: the SIMD each wave runs on
     __shared__ unsigned long long s_tb[8];   // diagnostics: the prologue's timeline
@@ -705,32 +709,52 @@ __global__ __launch_bounds__(NTHR) void k_replan_region(DevParams P, RegionJobs 
         if (tj < 0) return 2 * (J.nty + 2) + ti;                     // left column
         return 2 * (J.nty + 2) + J.ntx + ti;                         // right column
     };
-    constexpr int PER = (RTMAX * RTMAX * TT + NTHR - 1) / NTHR;      // elements per thread (16)
-    static_assert(NTHR == 1024 && TT % 256 == 0 && RBP % 4 == 0, "the block kernel deals its staging and write-back out by wave");
-    float init[PER];
-    int n_exp = 0;
-    // (the values HBM holds, for all of this thread's elements at once: asked for one after the other, each in front of its
-    //  comparison, they were nine memory round trips in a row.  A wave's 64 elements lie in one tile: which tile is scalar arithmetic.)
-#pragma unroll
-    for (int it = 0; it < PER; ++it) {
-        const int i = tid + it * NTHR, tl = __builtin_amdgcn_readfirstlane(i / TT);
-        init[it] = 0.0f;
-        if (tl >= ntl) continue;
-        const int e = i - tl * TT, ti = (tl * nty_magic) >> 16, tj = tl - ti * J.nty;
-        const size_t gt = (size_t)(gt0 + (J.tx0 + ti) * P.TY + J.ty0 + tj);
-        // the renewed back-pointers of the tile (a patch next to a changed one may lie in an unchanged tile)
-        if (S.tbp[tl]) P.bp[gt * TT + e] = Bb[(ti * T + e / T) * RBP + tj * T + e % T];
-        if (S.tflag[tl]) init[it] = P.G[gt * TT + e];
+    static_assert(NTHR == 1024 && TT % 64 == 0 && RBP % 4 == 0, "the block kernel deals its staging and write-back out by wave");
+    // (Round 4: this used to be two loops of 16 iterations per thread over ALL tiles of the largest block, unrolled so that the values HBM holds could wait in
+    //  registers between them -- 12 000 instructions of which a replan executes a sixth, fetched cold at every launch.  Now: the tiles that have something to
+    //  write are listed, what HBM holds of them goes straight into LDS (no register held, every load in flight at once), and one loop walks the list.)
+    constexpr int UPT = TT / 64;                                        // units (64 consecutive elements = one wave) per tile
+    const int wvw = __builtin_amdgcn_readfirstlane(tid >> 6), lnw = tid & 63;
+    if (tid < 64) {
+        const bool has = tid < ntl && (S.tflag[tid] | S.tbp[tid]);
+        const unsigned long long hm_ = __builtin_amdgcn_ballot_w64(has);
+        if (has) s_wbl[__popcll(hm_ & ((1ull << tid) - 1ull))] = tid;
+        if (tid == 0) s_nwb = __popcll(hm_);
     }
-#pragma unroll
-    for (int it = 0; it < PER; ++it) {
-        const int i = tid + it * NTHR, tl = __builtin_amdgcn_readfirstlane(i / TT);
-        if (tl >= ntl) continue;
-        const int e = i - tl * TT, ti = (tl * nty_magic) >> 16, tj = tl - ti * J.nty;
+    __syncthreads();
+    const int nunits = s_nwb * UPT;
+    auto unit_tile = [&](int u, int &k, int &part, int &tl, int &ti, int &tj) {      // (all wave-uniform)
+        k = u / UPT; part = u - k * UPT; tl = __builtin_amdgcn_readfirstlane(s_wbl[k]);
+        ti = (tl * nty_magic) >> 16; tj = tl - ti * J.nty;
+    };
+    {
+        typedef __attribute__((address_space(3))) void *lds_ptr;
+        typedef const __attribute__((address_space(1))) void *glb_ptr;
+#pragma unroll 1
+        for (int u = wvw; u < nunits; u += 16) {
+            int k, part, tl, ti, tj;
+            unit_tile(u, k, part, tl, ti, tj);
+            if (!S.tflag[tl] || k >= NG0) continue;
+            const size_t gt = (size_t)(gt0 + (J.tx0 + ti) * P.TY + J.ty0 + tj);
+            __builtin_amdgcn_global_load_lds((glb_ptr)(P.G + gt * TT + part * 64 + lnw), (lds_ptr)(G0c + k * TT + part * 64), 4, 0, 0);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __syncthreads();
+    int n_exp = 0;
+#pragma unroll 1
+    for (int u = wvw; u < nunits; u += 16) {
+        int k, part, tl, ti, tj;
+        unit_tile(u, k, part, tl, ti, tj);
+        const int e = part * 64 + lnw;
+        // the renewed back-pointers of the tile (a patch next to a changed one may lie in an unchanged tile)
+        if (S.tbp[tl]) P.bp[(size_t)(gt0 + (J.tx0 + ti) * P.TY + J.ty0 + tj) * TT + e] = Bb[(ti * T + e / T) * RBP + tj * T + e % T];
         if (!S.tflag[tl]) continue;                                         // nothing was applied in this tile
         const int tx = J.tx0 + ti, ty = J.ty0 + tj, gt = gt0 + tx * P.TY + ty;
         const int io_r = e / T, io_c = e % T;
-        const float gl0 = init[it];
+        float gl0;
+        if (k < NG0) gl0 = G0c[k * TT + e];
+        else { gl0 = P.G[(size_t)gt * TT + e]; P.Gprev[(size_t)gt * TT + e] = gl0; }      // (more changed tiles than the LDS copy holds: their old values go to the snapshot at once)
         const float gf = Gs[(ti * T + io_r + 1) * RP + tj * T + io_c + 1];
         if (gf == gl0) continue;
         ++n_exp;
@@ -903,14 +927,14 @@ __global__ __launch_bounds__(NTHR) void k_replan_region(DevParams P, RegionJobs 
     // not done: the launch chain takes over; the tiles changed here join the step's touched list with their values
     // as of the start of the step (num_nodes_expanded is counted against that snapshot at the end of the step)
     if (!S.done) {
-#pragma unroll
-        for (int it = 0; it < PER; ++it) {
-            const int i = tid + it * NTHR;
-            if (i >= ntl * TT) continue;
-            const int tl = i / TT, e = i - tl * TT;
+#pragma unroll 1
+        for (int u = wvw; u < nunits; u += 16) {
+            int k, part, tl, ti, tj;
+            unit_tile(u, k, part, tl, ti, tj);
             if (!S.tflag[tl]) continue;
-            const int gt = gt0 + (J.tx0 + tl / J.nty) * P.TY + J.ty0 + tl % J.nty;
-            P.Gprev[(size_t)gt * TT + e] = init[it];
+            const int e = part * 64 + lnw;
+            const int gt = gt0 + (J.tx0 + ti) * P.TY + J.ty0 + tj;
+            if (k < NG0) P.Gprev[(size_t)gt * TT + e] = G0c[k * TT + e];
             if (e == 0) {
                 P.fresh[gt] = 0;
                 if (atomicAdd(&P.touched[gt], 1) == 0) P.tlist[atomicAdd(&P.ctr->tcount, 1)] = gt;
