@@ -2,7 +2,9 @@
 agent-scope atomics -- argued, not release / acquire) against a checking build of the same source with the textbook fences
 (-DUFM_STRICT_FENCES: agent-scope release in front of every activation and lock release, acquire behind every take;
 unige-tasi-path-planners_amd/libufm_strict.so).  Same inputs, same scheduler forms (both wave counts, early hand-off and in-visit
-refresh on / off, helping on / off, a narrow band), whole fields compared bit for bit.  A one-off cross-check of the argument."""
+refresh on / off, helping on / off, a narrow band), whole fields compared bit for bit.  A one-off cross-check of the argument.
+The checking build also keeps only two tiles in the LDS copy of the block replan kernel's write-back (-DUFM_REGION_NG0=2: the product keeps 46), so the
+four replans of every case run the path of the tiles beyond the copy against the product's."""
 import os
 import subprocess
 import sys

@@ -367,7 +367,11 @@ __global__ __launch_bounds__(NTHR) void k_replan_region(DevParams P, RegionJobs 
     __shared__ __attribute__((aligned(16))) uint8_t Bb[RN * RBP];
     __shared__ RegionShared S;
     __shared__ int s_last;
+#ifdef UFM_REGION_NG0
+    constexpr int NG0 = UFM_REGION_NG0;              // (test builds: a small copy, so that the path of the tiles beyond it runs)
+#else
     constexpr int NG0 = (46 * 1024) / (TT * 4);      // tiles of the write-back's LDS copy of what HBM holds: what the CU's 160 KB leave (46 KB; a 6 x 6 block needs 36)
+#endif
     __shared__ float G0c[NG0 * TT];
     __shared__ int s_wbl[RTMAX * RTMAX];  // write-back: the tiles that have something to write
     __shared__ int s_nwb;
