@@ -70,6 +70,9 @@ constexpr int NTHR = 1024;     // 16 waves; four lanes per node, each wave owns 
 #define UFM_LOOK_SLEEP (UFM_LEAN_LOOKS ? 127 : 32)   // pause of a workgroup that found nothing to visit before it looks again (x 64 clocks; measured r2: 32 / 64 / 127 -> 15.0 / 14.9 / 14.9 ms)
 #endif
 #ifndef UFM_STEAL_VICTIMS
+#ifndef UFM_FOLLOW
+#define UFM_FOLLOW 1             // resident kernel: a workgroup with nothing of its own to go on with takes the neighbour it has just queued with the smallest priority (k_relax)
+#endif
 #define UFM_STEAL_VICTIMS 4    // owners whose words an idle workgroup looks at per look (k_relax, own_steal)
 #endif
 #ifndef UFM_EARLY_POLLS

@@ -53,7 +53,8 @@ struct Engine {
     hipEvent_t reg_ev[2] = {nullptr, nullptr};     // profiling: around the block kernel of a replan
     bool own_timed = false;
     int owned_flags = 0;             // resident kernel, diagnostics and variants.  1: no tile taken ahead; 2: no early hand-off (FD / SG); 4: early hand-off once per patch and visit;
-                                     // 8: early hand-off waits for its stores inside the sweep loop; 16: no in-visit halo refresh; 32: idle workgroups do not help out
+                                     // 8: early hand-off waits for its stores inside the sweep loop; 16: no in-visit halo refresh; 32: idle workgroups do not help out;
+                                     // 64: a workgroup does not follow the front (the neighbour it has just queued); 128: ... follows it beyond the ordering band too
     int owned_waves = 0;             // waves per tile visit of the resident kernel: 16 (256 workgroups), 8 (512), 0 = by the size of the job
     int dag_mode = 0;                // round 4 experiment: first visits gated by an arrival estimate.  0 off; 1: the estimate handed in through ufm_debug_set_tile_order
     bool dag_have = false;           // ... an estimate is in P.dag_a

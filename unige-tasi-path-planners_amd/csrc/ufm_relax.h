@@ -135,6 +135,7 @@ __global__ __launch_bounds__(OWNK == 2 ? NTHR / 2 : NTHR, UFM_RELAX_WAVES) void 
     int *const own_q = OWN ? P.own_prio + (size_t)blockIdx.x * P.own_slots : nullptr;
     const int own_base = OWN ? (int)blockIdx.x * P.own_slots : 0;
     int own_next = -1, own_slot_now = -1;   // (the same in every thread)
+    int prev_gt = -1;                       // the tile of the visit that has just ended (-1: none yet / it ended at the end condition)
     int own_hrot = 0;                       // which part of the hints the visit in progress has loaded ahead
     [[maybe_unused]] int look_rot = 0;      // ... and which part the look of an idle workgroup loads
     [[maybe_unused]] int held_looks = 0;    // P.dag_on: looks in a row that found only held tiles
@@ -157,6 +158,52 @@ __global__ __launch_bounds__(OWNK == 2 ? NTHR / 2 : NTHR, UFM_RELAX_WAVES) void 
             if (own_next >= 0 && s_own[3] >= INFBITS) own_next = -1;   // chosen ahead from the older copy of the words, but the take failed
             if (tid == 0 && s_own[1] >= 0) { s_own[0] = s_own[1]; s_own[1] = -1; }   // (at most one mark waits: own_commit ran since)
             if (NWV == 8 && own_next < 0) UFM_SETPRIO(0);                  // (looking for work: behind the waves of the CU's other visit)
+            // Following the front (round 4, second session; own_flags & 64 turns it off): a workgroup that has nothing of its own to go on with takes the neighbour it has
+            // just queued with the smallest priority -- the tile the front moves into -- by the ordinary take, instead of leaving it to its owner's next look
+            // (word, look, take: ~10 us of a ring's ~30 even with the chip nearly empty).  Inside the ordering band only (unless own_flags & 128).
+            if (UFM_FOLLOW && !(P.own_flags & 64) && own_next < 0 && prev_gt >= 0) {
+                if (w == 0) {
+                    const int pm = prev_gt / P.NTm, pt = prev_gt - pm * P.NTm, ptx = pt / P.TY, pty = pt - ptx * P.TY;
+                    unsigned long long key = ~0ull;
+                    if (lane < 9 && lane != 4) {
+                        const int ntx = ptx + lane / 3 - 1, nty = pty + lane % 3 - 1, pb = s_bmin[lane];
+                        if (pb != INFBITS && ntx >= 0 && ntx < P.TX && nty >= 0 && nty < P.TY) key = ((unsigned long long)(unsigned int)pb << 32) | (unsigned int)lane;
+                    }
+                    for (int o_ = 8; o_; o_ >>= 1) key = min(key, (unsigned long long)__shfl_xor((long long)key, o_));
+                    key = (unsigned long long)__shfl((long long)key, 0);
+                    const int fp = (int)(key >> 32);
+                    const int hint = (lane < UFM_HINT_SAMPLE && (lane + own_hrot * UFM_HINT_SAMPLE) % P.own_nw != (int)blockIdx.x) ? s_pfh[lane] : INFBITS;
+                    const bool beyond = key != ~0ull && hint != INFBITS && __int_as_float(fp) > __int_as_float(hint) + delta;
+                    const bool out = __ballot(beyond) != 0ull && !(P.own_flags & 128);
+                    if (lane == 0) {
+                        int gw = -1;
+#ifdef UFM_FOLLOW_STAT
+                        atomicAdd(&P.lmax[4000], 1);
+                        if (key == ~0ull) atomicAdd(&P.lmax[4001], 1); else if (out) atomicAdd(&P.lmax[4002], 1);
+#endif
+                        if (key != ~0ull && !out && !s_late) {
+                            const int d = (int)(unsigned int)key, ngt = pm * P.NTm + (ptx + d / 3 - 1) * P.TY + (pty + d % 3 - 1);
+                            int o_, sl_;
+                            own_locate(P, ngt, o_, sl_);
+                            const int cand = o_ * P.own_slots + sl_;
+                            int pr = fp, r_old, r_lk;
+                            own_take_issue(cand, pr, r_old, r_lk);
+                            if (own_take_resolve(cand, pr, r_old, r_lk)) {
+                                gw = cand; s_own[3] = pr;
+#ifdef UFM_FOLLOW_STAT
+                                atomicAdd(&P.lmax[4003], 1);
+#endif
+                                __hip_atomic_fetch_min(&P.own_min[blockIdx.x], pr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // what this workgroup holds now
+                            }
+                        }
+                        s_gmin = gw;
+                    }
+                }
+                __syncthreads();
+                const int fw = s_gmin;
+                __syncthreads();                               // (s_gmin is used again)
+                if (fw >= 0) own_next = __builtin_amdgcn_readfirstlane(fw);
+            }
             while (own_next < 0) {                             // nothing was taken ahead: look, wait, look again
                 __syncthreads();                               // LDS of the previous visit / round is free
                 // the other owners' hints.  (UFM_LEAN_LOOKS: a sample of them, another one at every look and in an order of this workgroup's own --
@@ -860,6 +907,7 @@ __global__ __launch_bounds__(OWNK == 2 ? NTHR / 2 : NTHR, UFM_RELAX_WAVES) void 
             if constexpr (OWN && DAG) if (tid != 4 && dag_nslot >= 0 && s_misc[0] && dag_mine < dag_nthr)      // first visit done: whoever waited for it has one less to wait for
                 __hip_atomic_fetch_sub(&P.dag_left[dag_nslot], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
+        if constexpr (OWN) prev_gt = gt;
 #ifdef UFM_TIMING
         if (MODE == MODE_LOWER) {
             const int dbg_ninf1 = __syncthreads_count(io_on && gf == INFINITY);
