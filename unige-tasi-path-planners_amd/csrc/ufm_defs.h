@@ -71,7 +71,8 @@ constexpr int NTHR = 1024;     // 16 waves; four lanes per node, each wave owns 
 #endif
 #ifndef UFM_STEAL_VICTIMS
 #ifndef UFM_FOLLOW
-#define UFM_FOLLOW 1             // resident kernel: a workgroup with nothing of its own to go on with takes the neighbour it has just queued with the smallest priority (k_relax)
+#define UFM_FOLLOW 3             // resident kernel: a workgroup with nothing of its own to go on with takes the neighbour it has just queued with the smallest priority (k_relax); the
+                                 // number of neighbours it tries (the best one is often in a visit already).  FD 4096^2 plan kernel 13.84 (0) / 13.6 (1) / 13.43 (2) / 13.36 (3) / 13.38 ms (8)
 #endif
 #define UFM_STEAL_VICTIMS 4    // owners whose words an idle workgroup looks at per look (k_relax, own_steal)
 #endif

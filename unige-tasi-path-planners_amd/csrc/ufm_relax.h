@@ -164,25 +164,24 @@ __global__ __launch_bounds__(OWNK == 2 ? NTHR / 2 : NTHR, UFM_RELAX_WAVES) void 
             if (UFM_FOLLOW && !(P.own_flags & 64) && own_next < 0 && prev_gt >= 0) {
                 if (w == 0) {
                     const int pm = prev_gt / P.NTm, pt = prev_gt - pm * P.NTm, ptx = pt / P.TY, pty = pt - ptx * P.TY;
-                    unsigned long long key = ~0ull;
+                    unsigned long long mine = ~0ull;
                     if (lane < 9 && lane != 4) {
                         const int ntx = ptx + lane / 3 - 1, nty = pty + lane % 3 - 1, pb = s_bmin[lane];
-                        if (pb != INFBITS && ntx >= 0 && ntx < P.TX && nty >= 0 && nty < P.TY) key = ((unsigned long long)(unsigned int)pb << 32) | (unsigned int)lane;
+                        if (pb != INFBITS && ntx >= 0 && ntx < P.TX && nty >= 0 && nty < P.TY) mine = ((unsigned long long)(unsigned int)pb << 32) | (unsigned int)lane;
                     }
-                    for (int o_ = 8; o_; o_ >>= 1) key = min(key, (unsigned long long)__shfl_xor((long long)key, o_));
-                    key = (unsigned long long)__shfl((long long)key, 0);
-                    const int fp = (int)(key >> 32);
                     const int hint = (lane < UFM_HINT_SAMPLE && (lane + own_hrot * UFM_HINT_SAMPLE) % P.own_nw != (int)blockIdx.x) ? s_pfh[lane] : INFBITS;
-                    const bool beyond = key != ~0ull && hint != INFBITS && __int_as_float(fp) > __int_as_float(hint) + delta;
-                    const bool out = __ballot(beyond) != 0ull && !(P.own_flags & 128);
-                    if (lane == 0) {
-                        int gw = -1;
-#ifdef UFM_FOLLOW_STAT
-                        atomicAdd(&P.lmax[4000], 1);
-                        if (key == ~0ull) atomicAdd(&P.lmax[4001], 1); else if (out) atomicAdd(&P.lmax[4002], 1);
-#endif
-                        if (key != ~0ull && !out && !s_late) {
-                            const int d = (int)(unsigned int)key, ngt = pm * P.NTm + (ptx + d / 3 - 1) * P.TY + (pty + d % 3 - 1);
+                    int gw = -1;
+#pragma unroll 1
+                    for (int attempt = 0; attempt < UFM_FOLLOW && gw < 0; ++attempt) {        // (the best neighbour may be in a visit already: then the next one)
+                        unsigned long long key = mine;
+                        for (int o_ = 8; o_; o_ >>= 1) key = min(key, (unsigned long long)__shfl_xor((long long)key, o_));
+                        key = (unsigned long long)__shfl((long long)key, 0);
+                        if (key == ~0ull) break;
+                        const int fp = (int)(key >> 32), d = (int)(unsigned int)key;
+                        const bool beyond = hint != INFBITS && __int_as_float(fp) > __int_as_float(hint) + delta;
+                        if ((__ballot(beyond) != 0ull && !(P.own_flags & 128)) || s_late) break;
+                        if (lane == 0) {
+                            const int ngt = pm * P.NTm + (ptx + d / 3 - 1) * P.TY + (pty + d % 3 - 1);
                             int o_, sl_;
                             own_locate(P, ngt, o_, sl_);
                             const int cand = o_ * P.own_slots + sl_;
@@ -190,14 +189,13 @@ __global__ __launch_bounds__(OWNK == 2 ? NTHR / 2 : NTHR, UFM_RELAX_WAVES) void 
                             own_take_issue(cand, pr, r_old, r_lk);
                             if (own_take_resolve(cand, pr, r_old, r_lk)) {
                                 gw = cand; s_own[3] = pr;
-#ifdef UFM_FOLLOW_STAT
-                                atomicAdd(&P.lmax[4003], 1);
-#endif
                                 __hip_atomic_fetch_min(&P.own_min[blockIdx.x], pr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // what this workgroup holds now
                             }
                         }
-                        s_gmin = gw;
+                        gw = __shfl(gw, 0);
+                        if (lane == d) mine = ~0ull;
                     }
+                    if (lane == 0) s_gmin = gw;
                 }
                 __syncthreads();
                 const int fw = s_gmin;
